@@ -1,0 +1,100 @@
+"""ctypes binding of libaldm_hip.so (the C-ABI declared in include/aldm_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaldm_hip.so")
+
+ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+OUT_BF16, OUT_F32 = 0, 1
+TILE_AUTO, TILE_128x128, TILE_64x64, TILE_128x64, TILE_64x128 = 0, 1, 2, 3, 4
+
+
+class IgemmArgs(C.Structure):
+    """Mirror of aldm_igemm_t (include/aldm_hip.h) -- field order and types must match exactly."""
+    _fields_ = [
+        ("x", C.c_void_p), ("x2", C.c_void_p),
+        ("B", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int), ("Cin2", C.c_int),
+        ("UH", C.c_int), ("UW", C.c_int),
+        ("w", C.c_void_p),
+        ("Kpad", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int), ("stride_h", C.c_int), ("stride_w", C.c_int),
+        ("pad_h", C.c_int), ("pad_w", C.c_int), ("dil_h", C.c_int), ("dil_w", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int),
+        ("in_act", C.c_int), ("in_slope", C.c_float),
+        ("lora_a", C.c_void_p), ("lora_b", C.c_void_p),
+        ("Rp", C.c_int),
+        ("lora_t_out", C.c_void_p),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p),
+        ("rowbias_ld", C.c_int),
+        ("geglu", C.c_int),
+        ("out_act", C.c_int), ("out_slope", C.c_float),
+        ("res", C.c_void_p), ("res2", C.c_void_p),
+        ("alpha", C.c_float),
+        ("out", C.c_void_p), ("out_dtype", C.c_int), ("out_ld", C.c_int),
+        ("out_batch_stride", C.c_longlong),
+        ("out_pix_stride", C.c_int), ("out_pix_offset", C.c_int),
+        ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_ld", C.c_int), ("vt_batch_stride", C.c_longlong),
+        ("splits", C.c_int), ("workspace", C.c_void_p),
+        ("tile", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/aldm_hip.h declares
+PROTOTYPES = {
+    "aldm_version": (C.c_char_p, []),
+    "aldm_last_error": (C.c_char_p, []),
+    "aldm_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
+    "aldm_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmArgs)]),
+    "aldm_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                 C.c_void_p]),
+    "aldm_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                    C.c_void_p]),
+    "aldm_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_silu": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "aldm_nchw_f32_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_float, C.c_void_p, C.c_void_p]),
+    "aldm_cfg_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aldm_advance_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_adamw_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+
+
+class AldmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AldmError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C audioldm_with_lora_amd/csrc`.  There is no CPU fallback on the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().aldm_last_error().decode()
+        raise AldmError(f"{what} failed (rc={rc}): {msg}")

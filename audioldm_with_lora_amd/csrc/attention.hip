@@ -1,0 +1,286 @@
+// Flash-style self-attention core for gfx950: S^T = K Q^T on v_mfma_f32_32x32x16_bf16 so that a lane owns ONE
+// query column -- running max / sum / rescale are lane-local (one cross-half shuffle per 64 keys), the fp32
+// score tile is converted in registers and re-used directly as the B operand of O^T += V^T P^T (no LDS round
+// trip for P; the key order inside each 16-wide K-step is the accumulator's row permutation, which the
+// V^T fragment reads reproduce with two 8-byte LDS reads).  K / V^T tiles of 64 keys are shared by the
+// workgroup's waves through padded (bank-conflict-free) LDS images, register-prefetched one tile ahead.
+//
+// Serves F.scaled_dot_product_attention inside diffusers AttnProcessor2_0 for the 32 Attention modules of
+// UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546].  Head dims 32/48/80
+// (8 heads at C = 256/384/640), sequence lengths 1000/252/64 (10 s) and 1024/256/64 (training).
+#include "common.h"
+
+namespace {
+
+constexpr int KV = 64;           // keys per tile
+constexpr int VS = 136;          // V^T LDS row stride in bytes (64 keys * 2 B + 8 B pad): conflict-free ds_read_b64
+
+template <int DP>
+struct AttnCfg {
+  static constexpr int DK = DP / 16;                       // QK^T k-steps
+  static constexpr int DT = (DP + 31) / 32;                // 32-row d-tiles of O^T
+  static constexpr int KS = DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);  // K LDS row stride (odd number of 16-B slots)
+  static constexpr int KBYTES = KV * KS;
+  static constexpr int VBYTES = DT * 32 * VS;
+  static constexpr int LDS = 2 * (KBYTES + VBYTES);
+};
+
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restrict__ q, int ldq,
+                                                            const bf16* __restrict__ k, int ldk,
+                                                            const bf16* __restrict__ vt, int vt_ld, long long vt_bs,
+                                                            int N, int D, float c /* scale*log2(e) */,
+                                                            bf16* __restrict__ out, int out_ld) {
+  using Cfg = AttnCfg<DP>;
+  constexpr int T = 64 * NW;
+  constexpr int DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS;
+  constexpr int KCH = KV * (DP / 8);        // 16-B chunks in a K tile
+  constexpr int VCH = DP * (KV / 8);        // 16-B chunks in a V^T tile
+  constexpr int KPT = (KCH + T - 1) / T, VPT = (VCH + T - 1) / T;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                              // [2][KV][KS]
+  char* Vs = smem + 2 * Cfg::KBYTES;            // [2][DT*32][VS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
+  const bf16* qb = q + (long long)b * N * ldq + head * D;
+  const bf16* kb = k + (long long)b * N * ldk + head * D;
+  const bf16* vb = vt + (long long)b * vt_bs + (long long)head * D * vt_ld;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // zero the d-padding rows of both V^T buffers once (rows D .. DT*32-1 stay zero for the whole kernel)
+  for (int i = tid; i < 2 * DT * 32 * (VS / 8); i += T) {
+    const int row = (i / (VS / 8)) % (DT * 32);
+    if (row >= D) reinterpret_cast<uint2*>(Vs)[i] = make_uint2(0u, 0u);
+  }
+
+  // Q fragments (B operand): lane (r, hh) holds Q[q0 + r][16 ks + 8 hh .. +7]
+  bf16x8 qf[DK];
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) {
+    const int col = 16 * ks + 8 * hh;
+    qf[ks] = (q0 + r < N && col < D) ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + r) * ldq + col) : zero8;
+  }
+
+  bf16x8 kreg[KPT], vreg[VPT];
+  auto prefetch = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int cidx = tid + i * T;
+      const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
+      bf16x8 v = zero8;
+      if (cidx < KCH && kv0 + row < N && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(kb + (long long)(kv0 + row) * ldk + ch * 8);
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int cidx = tid + i * T;
+      const int row = cidx >> 3, ch = cidx & 7;
+      bf16x8 v = zero8;
+      const int kvb = kv0 + ch * 8;
+      if (cidx < VCH && row < D && kvb < N) {
+        v = *reinterpret_cast<const bf16x8*>(vb + (long long)row * vt_ld + kvb);
+        if (kvb + 8 > N) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (kvb + j >= N) v[j] = (bf16)0.f;
+        }
+      }
+      vreg[i] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int cidx = tid + i * T;
+      const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
+      if (cidx < KCH) *reinterpret_cast<bf16x8*>(Ks + buf * Cfg::KBYTES + row * KS + ch * 16) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int cidx = tid + i * T;
+      const int row = cidx >> 3, ch = cidx & 7;
+      if (cidx < VCH) {
+        // rows are 136 B apart: 8-byte aligned only -> two 8-byte stores
+        uint2* dst = reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + row * VS + ch * 16);
+        const uint4 u = __builtin_bit_cast(uint4, vreg[i]);
+        dst[0] = make_uint2(u.x, u.y);
+        dst[1] = make_uint2(u.z, u.w);
+      }
+    }
+  };
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (N + KV - 1) / KV;
+  prefetch(0);
+  stage(0);
+  __syncthreads();
+
+  for (int it = 0; it < ntiles; ++it) {
+    const int buf = it & 1, kv0 = it * KV;
+    if (it + 1 < ntiles) prefetch(kv0 + KV);
+
+    // ---- S^T = K Q^T for two 32-key sub-tiles ----
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + buf * Cfg::KBYTES + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+      }
+    }
+    if (kv0 + KV > N) {  // tail tile: mask keys >= N
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kvr = kv0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kvr >= N) s[sub][i] = -INFINITY;
+        }
+    }
+    // ---- online softmax (lane-local: this lane's query column) ----
+    float mx = s[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * c);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][i], c, -m_new));
+        psum += pv;
+        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)pv;
+      }
+    l_run = l_run * alpha + psum;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {  // 4 K-steps of 16 keys
+        const char* vrow = Vs + buf * Cfg::VBYTES + (t * 32 + r) * VS + (16 * s2 + 4 * hh) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[t], 0, 0, 0);
+      }
+    if (it + 1 < ntiles) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q0 + r < N) {
+    bf16* orow = out + ((long long)b * N + q0 + r) * out_ld + head * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * hh;
+        if (d0 < D) {
+          bf16x4 v = {(bf16)(o[t][4 * g] * inv), (bf16)(o[t][4 * g + 1] * inv), (bf16)(o[t][4 * g + 2] * inv), (bf16)(o[t][4 * g + 3] * inv)};
+          *reinterpret_cast<bf16x4*>(orow + d0) = v;
+        }
+      }
+  }
+}
+
+template <int DP, int NW>
+int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
+                int H, int D, float scale, void* out, int out_ld, hipStream_t st) {
+  using Cfg = AttnCfg<DP>;
+  auto kern = attention_kernel<DP, NW>;
+  static bool attr_done = false;
+  if (!attr_done && Cfg::LDS > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    if (e != hipSuccess) { aldm_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  attr_done = true;
+  dim3 grid(cdiv(N, 32 * NW), H, B);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), Cfg::LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt,
+                     vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld);
+  return aldm_launch_status("attention");
+}
+
+template <int DP>
+int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
+                  int H, int D, float scale, void* out, int out_ld, hipStream_t st) {
+  if (N >= 512) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
+  if (N >= 128) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
+  return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
+}
+
+// ---- row softmax (VAE mid-block attention runs QK^T / PV through the GEMM kernel) ----
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int rows, int cols, int ld_in,
+                                                           float c, bf16* __restrict__ p, int ld_out) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* sr = s + (long long)row * ld_in;
+  float mx = -INFINITY;
+  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, sr[i]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = tid; i < cols; i += 256) sum += __builtin_amdgcn_exp2f((sr[i] - mx) * c);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  bf16* pr = p + (long long)row * ld_out;
+  for (int i = tid; i < ld_out; i += 256) pr[i] = i < cols ? (bf16)(__builtin_amdgcn_exp2f((sr[i] - mx) * c) * inv) : (bf16)0.f;
+}
+
+}  // namespace
+
+extern "C" int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                              long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                              void* stream) {
+  ALDM_CHECK_ARG(q && k && vt && out, "attention: null pointer");
+  ALDM_CHECK_ARG(B > 0 && N > 0 && H > 0 && d > 0, "attention: bad dims");
+  ALDM_CHECK_ARG(d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0, "attention: d/ld must be multiples of 8");
+  ALDM_CHECK_ARG(vt_ld >= ((N + 7) / 8) * 8, "attention: vt_ld %d too small for N %d", vt_ld, N);
+  hipStream_t st = (hipStream_t)stream;
+#define ALDM_ATTN(DPV) return launch_attn_d<DPV>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, st)
+  if (d <= 16) ALDM_ATTN(16);
+  if (d <= 32) ALDM_ATTN(32);
+  if (d <= 48) ALDM_ATTN(48);
+  if (d <= 64) ALDM_ATTN(64);
+  if (d <= 80) ALDM_ATTN(80);
+#undef ALDM_ATTN
+  aldm_set_error("attention: head dim %d > 80 is handled by the GEMM path", d);
+  return ALDM_E_UNSUPPORTED;
+}
+
+extern "C" int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out,
+                                 void* stream) {
+  ALDM_CHECK_ARG(s && p && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= cols, "softmax_rows: bad args");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, rows, cols, ld_in,
+                     scale * 1.44269504088896340736f, (bf16*)p, ld_out);
+  return aldm_launch_status("softmax_rows");
+}

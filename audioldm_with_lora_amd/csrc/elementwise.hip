@@ -1,0 +1,161 @@
+// Small fused elementwise kernels of the denoise loop and the training step (gfx950, HBM/latency-bound):
+// timestep embedding, SiLU, layout/precision boundary conversions, the fused CFG + DDIM update with a
+// device-side step counter (so one captured hipGraph replays all 200 steps), and flat AdamW.
+// [REF script/inference/generate_audio.py:47-52] (AudioLDMPipeline.__call__ loop body)
+// [REF script/train/train_audioldm_lora.py:396-403,563-565] (torch.optim.AdamW on the LoRA parameters)
+#include "common.h"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int t_stride, int B, int dim, bf16* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, i = idx - b * dim;
+  const int half = dim >> 1;
+  const int kf = i < half ? i : i - half;
+  const float freq = expf(-9.210340371976184f * (float)kf / (float)half);  // ln(10000)
+  const float arg = t[b * t_stride] * freq;
+  out[idx] = (bf16)(i < half ? cosf(arg) : sinf(arg));   // flip_sin_to_cos: [cos | sin]
+}
+
+__global__ void silu_kernel(const bf16* __restrict__ x, long long n, bf16* __restrict__ y) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (bf16)silu_f((float)v[k]);
+    *reinterpret_cast<bf16x8*>(y + i) = v;
+  } else {
+    for (long long j = i; j < n; ++j) y[j] = (bf16)silu_f((float)x[j]);
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, int HW, void* __restrict__ y, int y_f32) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over NHWC output
+  if (idx >= (long long)B * C * HW) return;
+  const int c = (int)(idx % C);
+  const long long t = idx / C;
+  const int p = (int)(t % HW), b = (int)(t / HW);
+  const float v = x[((long long)b * C + c) * HW + p];
+  if (y_f32) reinterpret_cast<float*>(y)[idx] = v; else reinterpret_cast<bf16*>(y)[idx] = (bf16)v;
+}
+
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, int x_f32, int B, int C, int HW, float* __restrict__ y) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over NCHW output
+  if (idx >= (long long)B * C * HW) return;
+  const int p = (int)(idx % HW);
+  const long long t = idx / HW;
+  const int c = (int)(t % C), b = (int)(t / C);
+  const long long src = ((long long)b * HW + p) * C + c;
+  y[idx] = x_f32 ? reinterpret_cast<const float*>(x)[src] : (float)reinterpret_cast<const bf16*>(x)[src];
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, long long n, float mul, bf16* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (bf16)(x[i] * mul);
+}
+
+__global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, float* __restrict__ x, int B, long long n, int cfg,
+                                     float g, const float* __restrict__ coef, const int* __restrict__ step_idx,
+                                     bf16* __restrict__ x_in) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * n;
+  if (idx >= total) return;
+  const float* cf = coef + 4 * step_idx[0];
+  const float sa = cf[0], sb = cf[1], sap = cf[2], sbp = cf[3];
+  float e;
+  if (cfg) {
+    const float eu = eps[idx], et = eps[total + idx];
+    e = eu + g * (et - eu);
+  } else {
+    e = eps[idx];
+  }
+  const float xv = x[idx];
+  const float x0 = (xv - sb * e) / sa;
+  const float xn = sap * x0 + sbp * e;
+  x[idx] = xn;
+  if (x_in) {
+    x_in[idx] = (bf16)xn;
+    if (cfg) x_in[total + idx] = (bf16)xn;
+  }
+}
+
+__global__ void advance_step_kernel(int* step_idx, const float* __restrict__ timesteps, int n_steps, float* t_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int i = step_idx[0] + 1;
+    step_idx[0] = i;
+    t_out[0] = timesteps[i < n_steps ? i : n_steps - 1];
+  }
+}
+
+__global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                                  float bc1, float bc2_sqrt, float gscale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // torch.optim.AdamW (decoupled weight decay), single-tensor formulation
+  const float grad = g[i] * gscale;
+  float pv = p[i] * (1.f - lr * wd);
+  const float mv = b1 * m[i] + (1.f - b1) * grad;
+  const float vv = b2 * v[i] + (1.f - b2) * grad * grad;
+  m[i] = mv; v[i] = vv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  pv -= (lr / bc1) * (mv / denom);
+  p[i] = pv;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int aldm_timestep_embedding(const float* t, int t_stride, int B, int dim, void* out, void* stream) {
+  ALDM_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0 && (t_stride == 0 || t_stride == 1), "timestep_embedding: bad args");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(blocks_for((long long)B * dim, 256)), dim3(256), 0, (hipStream_t)stream, t, t_stride, B, dim, (bf16*)out);
+  return aldm_launch_status("timestep_embedding");
+}
+
+extern "C" int aldm_silu(const void* x, long long n, void* y, void* stream) {
+  ALDM_CHECK_ARG(x && y && n > 0, "silu: bad args");
+  hipLaunchKernelGGL(silu_kernel, dim3(blocks_for((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n, (bf16*)y);
+  return aldm_launch_status("silu");
+}
+
+extern "C" int aldm_nchw_f32_to_nhwc(const float* x, int B, int C, int HW, void* y, int y_is_f32, void* stream) {
+  ALDM_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0, "nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for((long long)B * C * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, y, y_is_f32);
+  return aldm_launch_status("nchw_to_nhwc");
+}
+
+extern "C" int aldm_nhwc_to_nchw_f32(const void* x, int x_is_f32, int B, int C, int HW, float* y, void* stream) {
+  ALDM_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks_for((long long)B * C * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, B, C, HW, y);
+  return aldm_launch_status("nhwc_to_nchw");
+}
+
+extern "C" int aldm_f32_to_bf16(const float* x, long long n, float mul, void* y, void* stream) {
+  ALDM_CHECK_ARG(x && y && n > 0, "f32_to_bf16: bad args");
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, mul, (bf16*)y);
+  return aldm_launch_status("f32_to_bf16");
+}
+
+extern "C" int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance,
+                                  const float* coef, const int* step_idx, void* x_in_bf16, void* stream) {
+  ALDM_CHECK_ARG(eps && x && coef && step_idx && B > 0 && n_per_sample > 0, "cfg_ddim_step: bad args");
+  hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg, guidance, coef, step_idx, (bf16*)x_in_bf16);
+  return aldm_launch_status("cfg_ddim_step");
+}
+
+extern "C" int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream) {
+  ALDM_CHECK_ARG(step_idx && timesteps && t_out && n_steps > 0, "advance_step: bad args");
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_idx, timesteps, n_steps, t_out);
+  return aldm_launch_status("advance_step");
+}
+
+extern "C" int aldm_adamw_flat(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  ALDM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw_flat: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  return aldm_launch_status("adamw_flat");
+}

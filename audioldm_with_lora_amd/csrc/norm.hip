@@ -1,0 +1,162 @@
+// GroupNorm(+SiLU) and LayerNorm for channels-last bf16 activations on gfx950.
+// HBM/L2-bound kernels: 8-byte (4-channel) accesses for GroupNorm strips, 16-byte rows for LayerNorm,
+// fp32 statistics, two-pass (mean, then centred variance) out of an LDS copy of the strip when it fits.
+//
+// GroupNorm serves F.group_norm in ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out and
+// the VAE's group norms; LayerNorm serves BasicTransformerBlock.norm1/2/3 -- all under
+// UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546] /
+// AutoencoderKL.decode [REF script/inference/generate_audio.py:47-52].
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 512;
+constexpr int GN_LDS_QUADS = 16384;  // 128 KiB of bf16x4 strip cache
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid, int nthreads) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nthreads / 64; ++i) t += red[i];
+  return t;
+}
+
+// One workgroup per (batch, group).  A "quad" is 4 consecutive channels of one pixel (8 bytes); every
+// group width used by the models is a multiple of 4 and so is the concat boundary C1.
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x2,
+                                                               int HW, int C1, int C2, int groups, float eps,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act,
+                                                               bf16* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x4* cache = reinterpret_cast<bf16x4*>(smem);
+  float* red = reinterpret_cast<float*>(smem + (size_t)GN_LDS_QUADS * 8);
+
+  const int C = C1 + C2;
+  const int Cg = C / groups, qpp = Cg >> 2;  // quads per pixel in this group
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  const int c0 = g * Cg;
+  const int nquads = HW * qpp;
+  const bool cached = nquads <= GN_LDS_QUADS;
+  const int tid = threadIdx.x;
+
+  auto load_quad = [&](int q) -> bf16x4 {
+    const int pix = q / qpp, j = q - pix * qpp;
+    const int c = c0 + 4 * j;
+    if (c < C1) return *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c);
+    return *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
+  };
+
+  float s = 0.f;
+  for (int q = tid; q < nquads; q += GN_THREADS) {
+    const bf16x4 v = load_quad(q);
+    if (cached) cache[q] = v;
+    s += (float)v[0] + (float)v[1] + (float)v[2] + (float)v[3];
+  }
+  const float n = (float)nquads * 4.f;
+  const float mean = block_sum(s, red, tid, GN_THREADS) / n;
+  float ss = 0.f;
+  for (int q = tid; q < nquads; q += GN_THREADS) {
+    const bf16x4 v = cached ? cache[q] : load_quad(q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = (float)v[k] - mean; ss += d * d; }
+  }
+  const float var = block_sum(ss, red, tid, GN_THREADS) / n;
+  const float rstd = rsqrtf(var + eps);
+
+  for (int q = tid; q < nquads; q += GN_THREADS) {
+    const bf16x4 v = cached ? cache[q] : load_quad(q);
+    const int pix = q / qpp, j = q - pix * qpp;
+    const int c = c0 + 4 * j;
+    bf16x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gm = gamma[c + k] * rstd;
+      float t = ((float)v[k] - mean) * gm + beta[c + k];
+      if (act == ALDM_ACT_SILU) t = silu_f(t);
+      o[k] = (bf16)t;
+    }
+    *reinterpret_cast<bf16x4*>(y + ((long long)b * HW + pix) * C + c) = o;
+  }
+}
+
+// LayerNorm: one wave per row, 16-byte chunks, C <= 64*8*MAXC.
+constexpr int LN_MAXC = 4;  // chunks per lane -> C <= 2048
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int M, int C,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        bf16* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C >> 3;
+  const bf16* xr = x + (long long)row * C;
+  bf16x8 v[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      v[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += (float)v[i][k];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = (float)v[i][k] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  bf16* yr = y + (long long)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = ch * 8 + k;
+        o[k] = (bf16)(((float)v[i][k] - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2, int groups, float eps,
+                              const float* gamma, const float* beta, int act, void* y, void* stream) {
+  ALDM_CHECK_ARG(x && y && gamma && beta, "groupnorm: null pointer");
+  ALDM_CHECK_ARG(B > 0 && HW > 0 && C1 > 0 && C2 >= 0 && groups > 0, "groupnorm: bad dims");
+  const int C = C1 + C2;
+  ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0, "groupnorm: group width %d / C1 %d must be multiples of 4", C / groups, C1);
+  ALDM_CHECK_ARG(C2 == 0 || x2, "groupnorm: C2 without x2");
+  const size_t lds = (size_t)GN_LDS_QUADS * 8 + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(groupnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { aldm_set_error("groupnorm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16*)x,
+                     (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y);
+  return aldm_launch_status("groupnorm");
+}
+
+extern "C" int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,
+                              void* stream) {
+  ALDM_CHECK_ARG(x && y && gamma && beta && M > 0, "layernorm: null pointer / bad M");
+  ALDM_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "layernorm: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXC);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, M, C, gamma,
+                     beta, eps, (bf16*)y);
+  return aldm_launch_status("layernorm");
+}

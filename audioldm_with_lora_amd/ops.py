@@ -1,0 +1,300 @@
+"""Tensor-level wrappers over the C-ABI (include/aldm_hip.h).
+
+torch is used for device memory and the current stream only; all arithmetic happens in the HIP
+kernels.  Activations are channels-last bf16 tensors: images [B, H, W, C], token sequences [B*N, C].
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_SILU, ACT_TANH, OUT_BF16, OUT_F32, IgemmArgs, check)
+
+BK = 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.AldmError("the product path runs on the MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+@dataclass
+class PackedW:
+    """bf16 weights packed for aldm_igemm: w [N][Kpad] (K = (kh*KW+kw)*Cin + c), fp32 bias."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    N: int
+    Cin: int            # total input channels (both concat sources)
+    KH: int = 1
+    KW: int = 1
+    geglu: bool = False
+    lora_a: Optional[torch.Tensor] = None      # [Rp][Kpad] bf16
+    lora_b: Optional[torch.Tensor] = None      # [N][Rp] bf16, pre-scaled by alpha/r
+    Rp: int = 0
+
+    @property
+    def Kpad(self):
+        return self.w.shape[1]
+
+
+def _pad_k(w2d: torch.Tensor) -> torch.Tensor:
+    n, k = w2d.shape
+    kp = (k + BK - 1) // BK * BK
+    out = torch.zeros(n, kp, dtype=torch.bfloat16, device=w2d.device)
+    out[:, :k] = w2d.to(torch.bfloat16)
+    return out.contiguous()
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedW:
+    """Conv2d weight [Cout, Cin, KH, KW] -> [Cout][(kh, kw, cin)]."""
+    co, ci, kh, kw = weight.shape
+    w = _pad_k(weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci))
+    return PackedW(w, None if bias is None else bias.detach().float().contiguous(), co, ci, kh, kw)
+
+
+def pack_conv1d(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedW:
+    """Conv1d weight [Cout, Cin, K] -> KH = 1, KW = K."""
+    return pack_conv(weight.unsqueeze(2), bias)
+
+
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedW:
+    n, k = weight.shape
+    return PackedW(_pad_k(weight.detach()), None if bias is None else bias.detach().float().contiguous(), n, k)
+
+
+def pack_geglu(weight: torch.Tensor, bias: torch.Tensor) -> PackedW:
+    """GEGLU.proj [2*inner, C]: rows re-ordered into blocks of (16 value | 16 gate) so that a lane holds
+    a value and its gate in adjacent MFMA tiles (value = first half, gate = second half)."""
+    two_inner, k = weight.shape
+    inner = two_inner // 2
+    assert inner % 16 == 0
+    idx = torch.arange(inner, device=weight.device).view(-1, 16)
+    order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+    pw = PackedW(_pad_k(weight.detach()[order]), bias.detach().float()[order].contiguous(), two_inner, k)
+    pw.geglu = True
+    return pw
+
+
+def attach_lora(pw: PackedW, parts):
+    """parts: list of (row_offset, n_rows, A [r, K], B [n_rows, r], scaling) -- one per LoRA-wrapped target
+    that shares this GEMM.  Builds A_cat [Rp][Kpad] and the block-structured, pre-scaled B_ext [N][Rp]."""
+    parts = [p for p in parts if p is not None]
+    if not parts:
+        pw.lora_a = pw.lora_b = None
+        pw.Rp = 0
+        return pw
+    rtot = sum(p[2].shape[0] for p in parts)
+    rp = 32 if rtot <= 32 else 64
+    if rtot > 64:
+        raise _lib.AldmError(f"fused LoRA supports a combined rank <= 64 per GEMM (got {rtot})")
+    dev = pw.w.device
+    a = torch.zeros(rp, pw.Kpad, dtype=torch.bfloat16, device=dev)
+    b = torch.zeros(pw.N, rp, dtype=torch.bfloat16, device=dev)
+    col = 0
+    for row0, nrows, A, Bm, s in parts:
+        r, k = A.shape
+        a[col:col + r, :k] = A.detach().to(torch.bfloat16)
+        b[row0:row0 + nrows, col:col + r] = (Bm.detach().float() * s).to(torch.bfloat16)
+        col += r
+    pw.lora_a, pw.lora_b, pw.Rp = a.contiguous(), b.contiguous(), rp
+    return pw
+
+
+def auto_splits(M, N, ktiles):
+    """Split-K heuristic for the low-resolution UNet levels (few output tiles, deep K)."""
+    tiles = math.ceil(M / 64) * math.ceil(N / 64)
+    if tiles >= 160 or ktiles < 16:
+        return 1
+    return max(1, min(8, 384 // tiles, ktiles // 8))
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, stride=(1, 1), pad=(0, 0), dil=(1, 1),
+         up_size=None, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
+         out_slope=0.0, res=None, res2=None, alpha=1.0, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
+         out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
+         splits=None, tile=0):
+    """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2])."""
+    _require_gpu(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    B, IH, IW, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        assert x2.dtype == torch.bfloat16 and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
+        C2 = x2.shape[3]
+    assert C1 + C2 == pw.Cin, f"conv: input channels {C1}+{C2} != packed {pw.Cin}"
+    KH, KW = pw.KH, pw.KW
+    VH, VW = (up_size if up_size is not None else (IH, IW))
+    if out_hw is None:
+        OH = (VH + 2 * pad[0] - dil[0] * (KH - 1) - 1) // stride[0] + 1
+        OW = (VW + 2 * pad[1] - dil[1] * (KW - 1) - 1) // stride[1] + 1
+    else:
+        OH, OW = out_hw
+    ncols = pw.N // 2 if pw.geglu else pw.N
+    if vt is not None:
+        ncols = vt_col0
+    if out_ld is None:
+        out_ld = ncols
+    if out is None:
+        out = torch.empty(B, OH, OW, out_ld, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    if out_batch_stride is None:
+        assert out_pix_stride == 1 and out_pix_offset == 0, "strided output rows need an explicit batch stride"
+        out_batch_stride = OH * OW * out_ld
+    a = IgemmArgs()
+    a.x, a.x2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
+    a.B, a.IH, a.IW, a.Cin, a.Cin2 = B, IH, IW, C1, C2
+    a.UH, a.UW = (up_size if up_size is not None else (0, 0))
+    a.w, a.Kpad = pw.w.data_ptr(), pw.Kpad
+    a.KH, a.KW = KH, KW
+    a.stride_h, a.stride_w = stride
+    a.pad_h, a.pad_w = pad
+    a.dil_h, a.dil_w = dil
+    a.OH, a.OW, a.Cout = OH, OW, pw.N
+    a.in_act, a.in_slope = in_act, in_slope
+    if pw.Rp:
+        a.lora_a, a.lora_b, a.Rp = pw.lora_a.data_ptr(), pw.lora_b.data_ptr(), pw.Rp
+        a.lora_t_out = lora_t_out.data_ptr() if lora_t_out is not None else None
+    a.bias = pw.bias.data_ptr() if pw.bias is not None else None
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32
+        a.rowbias, a.rowbias_ld = rowbias.data_ptr(), rowbias_ld
+    a.geglu = 1 if pw.geglu else 0
+    a.out_act, a.out_slope = out_act, out_slope
+    a.res = res.data_ptr() if res is not None else None
+    a.res2 = res2.data_ptr() if res2 is not None else None
+    a.alpha = alpha
+    a.out, a.out_dtype, a.out_ld = out.data_ptr(), (OUT_F32 if out.dtype == torch.float32 else OUT_BF16), out_ld
+    a.out_batch_stride = out_batch_stride
+    a.out_pix_stride, a.out_pix_offset = out_pix_stride, out_pix_offset
+    if vt is not None:
+        a.vt, a.vt_col0, a.vt_ld, a.vt_batch_stride = vt.data_ptr(), vt_col0, vt_ld, vt_batch_stride
+    M = B * OH * OW
+    ktiles = pw.Kpad // BK
+    if splits is None:
+        splits = 1 if (vt is not None or pw.N % 4) else auto_splits(M, pw.N, ktiles)
+    a.splits = splits
+    if splits > 1:
+        ws = _workspace(splits * M * pw.N * 4, x.device)
+        a.workspace = ws.data_ptr()
+    a.tile = tile
+    check(_lib.load().aldm_igemm(C.byref(a), _stream()), "aldm_igemm")
+    return out
+
+
+def linear(x2d: torch.Tensor, pw: PackedW, **kw):
+    """x2d [M, K] bf16 -> [M, N]; thin view over conv with a 1x1 filter."""
+    M, K = x2d.shape
+    out = kw.pop("out", None)
+    y = conv(x2d.view(1, 1, M, K), pw, out=(None if out is None else out), **kw)
+    return y if out is not None else y.view(M, -1)
+
+
+def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
+    _require_gpu(x)
+    B, H, W, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().aldm_groupnorm(_p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y),
+                                     _stream()), "aldm_groupnorm")
+    return y
+
+
+def layernorm(x2d, gamma, beta, eps=1e-5):
+    _require_gpu(x2d)
+    M, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    check(_lib.load().aldm_layernorm(_p(x2d), M, Cc, _p(gamma), _p(beta), eps, _p(y), _stream()), "aldm_layernorm")
+    return y
+
+
+def attention(qk, vt, B, N, H, d, out=None):
+    """qk [B*N, 2C] (Q | K), vt [B, C, Npad]; returns [B*N, C]."""
+    _require_gpu(qk)
+    Cc = H * d
+    if out is None:
+        out = torch.empty(B * N, Cc, dtype=torch.bfloat16, device=qk.device)
+    q_ptr = C.c_void_p(qk.data_ptr())
+    k_ptr = C.c_void_p(qk.data_ptr() + Cc * 2)
+    check(_lib.load().aldm_attention(q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N,
+                                     H, d, 1.0 / math.sqrt(d), _p(out), Cc, _stream()), "aldm_attention")
+    return out
+
+
+def softmax_rows(s, scale, cols, ld_out):
+    rows = s.shape[0]
+    p = torch.empty(rows, ld_out, dtype=torch.bfloat16, device=s.device)
+    check(_lib.load().aldm_softmax_rows(_p(s), rows, cols, s.shape[1], scale, _p(p), ld_out, _stream()),
+          "aldm_softmax_rows")
+    return p
+
+
+def timestep_embedding(t_dev, B, dim):
+    out = torch.empty(B, dim, dtype=torch.bfloat16, device=t_dev.device)
+    stride = 0 if t_dev.numel() == 1 else 1
+    check(_lib.load().aldm_timestep_embedding(_p(t_dev), stride, B, dim, _p(out), _stream()), "aldm_timestep_embedding")
+    return out
+
+
+def nchw_to_nhwc(x_f32, out_f32=False):
+    _require_gpu(x_f32)
+    B, Cc, H, W = x_f32.shape
+    y = torch.empty(B, H, W, Cc, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_f32.device)
+    check(_lib.load().aldm_nchw_f32_to_nhwc(_p(x_f32.contiguous()), B, Cc, H * W, _p(y), int(out_f32), _stream()),
+          "aldm_nchw_f32_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw_f32(x):
+    _require_gpu(x)
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    check(_lib.load().aldm_nhwc_to_nchw_f32(_p(x.contiguous()), int(x.dtype == torch.float32), B, Cc, H * W, _p(y),
+                                            _stream()), "aldm_nhwc_to_nchw_f32")
+    return y
+
+
+def f32_to_bf16(x, mul=1.0, out=None):
+    _require_gpu(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().aldm_f32_to_bf16(_p(x), x.numel(), mul, _p(out), _stream()), "aldm_f32_to_bf16")
+    return out
+
+
+def cfg_ddim_step(eps, x, cfg, guidance, coef, step_idx, x_in):
+    B = x.shape[0]
+    n = x.numel() // B
+    check(_lib.load().aldm_cfg_ddim_step(_p(eps), _p(x), B, n, int(cfg), guidance, _p(coef), _p(step_idx), _p(x_in),
+                                         _stream()), "aldm_cfg_ddim_step")
+
+
+def advance_step(step_idx, timesteps_f32, t_out):
+    check(_lib.load().aldm_advance_step(_p(step_idx), _p(timesteps_f32), timesteps_f32.numel(), _p(t_out), _stream()),
+          "aldm_advance_step")
+
+
+def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    check(_lib.load().aldm_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+                                      grad_scale, _stream()), "aldm_adamw_flat")

@@ -1,0 +1,153 @@
+/*
+ * aldm_hip.h -- C-ABI of the MI355X-native AudioLDM+LoRA hot path (libaldm_hip.so).
+ *
+ * The reference (2025-comprehensive-design/AudioLDM-with-LoRA) has no FFI of its own: its hot
+ * path is reached through the Python objects of diffusers / peft / transformers
+ * (SURVEY.md section 8b).  Each entry point below replaces the device arithmetic behind one of
+ * those calls; the reference call site it serves is cited per function.  A maintainer binds
+ * them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise
+ *   - the caller owns every buffer; nothing is allocated, freed or retained here
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*), contain no host
+ *     synchronisation and are safe under hipGraph stream capture
+ *   - return 0 on success, a negative ALDM_E_* on bad arguments, a positive hipError_t otherwise
+ *   - activations are channels-last bf16: images [B][H][W][C], sequences [B][T][C]
+ *   - weights are bf16, pre-packed once by the host into [N][Kpad] (K contiguous, Kpad % 64 == 0)
+ */
+#ifndef ALDM_HIP_H
+#define ALDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALDM_OK 0
+#define ALDM_E_ARG (-1)      /* inconsistent sizes / null pointer */
+#define ALDM_E_ALIGN (-2)    /* channel counts or pointers not 16-byte friendly */
+#define ALDM_E_UNSUPPORTED (-3)
+
+enum { ALDM_ACT_NONE = 0, ALDM_ACT_SILU = 1, ALDM_ACT_LRELU = 2, ALDM_ACT_TANH = 3 };
+enum { ALDM_OUT_BF16 = 0, ALDM_OUT_F32 = 1 };
+
+const char* aldm_version(void);
+const char* aldm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear on MFMA (bf16 in, fp32 accumulate).
+ *   out[row(b,oh,ow)][n] = epilogue( sum_{kh,kw,c} X[b][ih][iw][c] * W[n][(kh*KW+kw)*Ctot + c] )
+ *   ih = oh*stride_h + kh*dil_h - pad_h   (after the optional nearest-upsample map, below)
+ * Serves: every F.conv2d / F.linear / conv1d / conv_transpose1d phase under
+ *   UNet2DConditionModel.forward   [REF script/train/train_audioldm_lora.py:539-546]
+ *   AutoencoderKL.decode, SpeechT5HifiGan.forward inside AudioLDMPipeline.__call__
+ *                                   [REF script/inference/generate_audio.py:47-52]
+ * and, with lora_a/lora_b set, peft lora.Linear.forward  y = Wx + (alpha/r) B(Ax)
+ *                                   [REF script/train/train_audioldm_lora.py:378-385]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  /* input: source 1 (+ optional source 2 = virtual channel concat [x | x2]) */
+  const void* x;  const void* x2;
+  int B, IH, IW, Cin, Cin2;
+  int UH, UW;               /* >0: conv runs on the nearest-upsampled image of this size */
+  /* filter */
+  const void* w;            /* [Cout][Kpad] bf16, K index = (kh*KW+kw)*(Cin+Cin2) + c */
+  int Kpad;
+  int KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;   /* dil may be negative */
+  int OH, OW, Cout;
+  int in_act;  float in_slope;      /* activation applied to X while it is gathered (vocoder leaky-relu) */
+  /* LoRA side channel (linear layers): T = X A^T, acc += T B'^T with B' = (alpha/r) B */
+  const void* lora_a;       /* [Rp][Kpad] bf16 */
+  const void* lora_b;       /* [Cout][Rp] bf16, pre-scaled */
+  int Rp;                   /* 0, 32 or 64 */
+  void* lora_t_out;         /* optional [M][Rp] bf16 copy of T (training saves it) */
+  /* epilogue: v = acc + bias[n] + rowbias[b][n];  GEGLU (optional);  v = out_act(v);
+     v = alpha*(v + res) + res2;  store                                              */
+  const float* bias;        /* [Cout] fp32 or null */
+  const float* rowbias;     /* [B][rowbias_ld] fp32 or null (time-embedding projection) */
+  int rowbias_ld;
+  int geglu;                /* 1: W rows interleaved (16 value | 16 gate); out has Cout/2 columns */
+  int out_act;  float out_slope;
+  const void* res;  const void* res2;   /* bf16, addressed exactly like out */
+  float alpha;
+  void* out;  int out_dtype;  int out_ld;           /* columns per output row */
+  long long out_batch_stride;                       /* elements between batches */
+  int out_pix_stride, out_pix_offset;               /* row = pix*stride + offset (conv_transpose phases) */
+  /* columns >= vt_col0 (multiple of 16) are stored transposed: vt[b][n - vt_col0][pix] bf16 */
+  void* vt;  int vt_col0;  int vt_ld;  long long vt_batch_stride;
+  /* split-K */
+  int splits;  float* workspace;                    /* [splits][M][Cout] fp32 when splits > 1 */
+  int tile;                 /* 0 = auto, else ALDM_TILE_* */
+} aldm_igemm_t;
+
+enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
+       ALDM_TILE_32x64 = 5 };
+
+int aldm_igemm(const aldm_igemm_t* p, void* stream);
+size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) over channels-last x [B][HW][C1] (optionally the virtual channel
+ * concat [x | x2], C = C1 + C2) -> y [B][HW][C] bf16.  One workgroup per (batch, group); stats in fp32.
+ * F.group_norm under ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out, VAE group_norm
+ * [REF script/train/train_audioldm_lora.py:539-546] (inside UNet2DConditionModel.forward)
+ * ------------------------------------------------------------------------------------------ */
+int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2, int groups, float eps,
+                   const float* gamma, const float* beta, int act, void* y, void* stream);
+
+/* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
+int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash-style multi-head self-attention core (F.scaled_dot_product_attention in diffusers
+ * AttnProcessor2_0; 32 Attention modules per UNet forward).
+ *   q,k: bf16 rows [B*N][ld*], head h at columns h*d .. h*d+d-1 ;  vt: [B][H*d][vt_ld] (token-contiguous V^T)
+ *   out[b*N + n][h*d + i] bf16, ld = out_ld.  softmax scale = scale (1/sqrt(d)).
+ * ------------------------------------------------------------------------------------------ */
+int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                   long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                   void* stream);
+
+/* Row softmax of fp32 scores [rows][cols] (ld) -> bf16 probabilities (VAE mid-block attention, N=4000, d=512). */
+int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small fused elementwise kernels.
+ * ------------------------------------------------------------------------------------------ */
+/* sinusoidal timestep embedding [cos | sin] (diffusers Timesteps, flip_sin_to_cos) -> bf16 [B][dim]
+   t: device fp32 [B] or [1] (t_stride 0/1). */
+int aldm_timestep_embedding(const float* t, int t_stride, int B, int dim, void* out, void* stream);
+/* y = silu(x) bf16 elementwise */
+int aldm_silu(const void* x, long long n, void* y, void* stream);
+/* NCHW fp32 <-> channels-last boundary conversions (the pipeline's public tensors are NCHW fp32) */
+int aldm_nchw_f32_to_nhwc(const float* x, int B, int C, int HW, void* y, int y_is_f32, void* stream);
+int aldm_nhwc_to_nchw_f32(const void* x, int x_is_f32, int B, int C, int HW, float* y, void* stream);
+/* y_bf16 = (bf16)(x_f32 * mul), n elements */
+int aldm_f32_to_bf16(const float* x, long long n, float mul, void* y, void* stream);
+/* classifier-free guidance + DDIM step (eta = 0), the AudioLDMPipeline.__call__ loop body
+   [REF script/inference/generate_audio.py:47-52], elementwise over channels-last fp32 latents:
+     eps = eps_u + g (eps_t - eps_u)                       (cfg != 0; eps holds [uncond | text] halves)
+     x0  = (x - sqrt(1-a_t) eps) / sqrt(a_t) ;  x' = sqrt(a_p) x0 + sqrt(1-a_p) eps
+   coef: device fp32 table [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_p), sqrt(1-a_p)}; the row is
+   selected ON DEVICE by step_idx[0], so a captured hipGraph replays every step unchanged.
+   x (fp32, [B][n]) is updated in place; x_in (bf16, [2B][n] if cfg else [B][n]) receives the next UNet input. */
+int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance,
+                       const float* coef, const int* step_idx, void* x_in_bf16, void* stream);
+/* device-side loop counter for graph replay: step_idx[0] += 1 ; t_out[0] = timesteps[min(step_idx, n-1)] */
+int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training helpers (configs 3/4): fused AdamW over one flat fp32 LoRA buffer
+ * (torch.optim.AdamW, [REF script/train/train_audioldm_lora.py:396-403,563-565]).
+ * ------------------------------------------------------------------------------------------ */
+int aldm_adamw_flat(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,228 @@
+"""GPU parity: each HIP kernel (through the C-ABI) vs a plain torch-CPU fp32 reference of the same op on
+bf16-rounded inputs.  Tolerances: outputs are bf16 (8 significant bits) with fp32 accumulation, so the
+bound is |err| <= rtol*|ref| + atol with rtol ~ 2^-7 and atol a small fraction of the output range
+(accumulated rounding of bf16 intermediates)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def close(got, want, rtol=1.2e-2, atol=None):
+    want = want.float()
+    got = got.float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if atol is None:
+        atol = 8e-3 * float(want.abs().max()) + 1e-6
+    err = (got - want).abs()
+    bound = atol + rtol * want.abs()
+    bad = ~(err <= bound)
+    assert not bad.any(), f"max err {float(err.max()):.4g} (ref max {float(want.abs().max()):.4g}), {int(bad.sum())} bad"
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def to_nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from audioldm_with_lora_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride,tile", [
+    (2, 64, 128, 25, 16, 1, 0), (1, 128, 64, 9, 4, 1, 0), (2, 8, 128, 31, 16, 1, 0), (2, 192, 256, 16, 8, 2, 0),
+    (8, 128, 128, 50, 16, 1, 1), (2, 128, 128, 13, 7, 1, 3), (2, 128, 128, 13, 7, 1, 4), (1, 640, 320, 32, 2, 1, 2),
+    (1, 128, 8, 20, 16, 1, 0),
+])
+def test_conv3x3(ops, B, Cin, Cout, H, W, stride, tile):
+    g = torch.Generator().manual_seed(0)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    want = F.conv2d(x, w, b, stride=stride, padding=1)
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    y = ops.conv(nhwc(x), pw, stride=(stride, stride), pad=(1, 1), tile=tile)
+    close(to_nchw(y), want)
+
+
+def test_conv_splitk_matches(ops):
+    g = torch.Generator().manual_seed(1)
+    x = bf(torch.randn(2, 320, 16, 2, generator=g))
+    w = bf(torch.randn(160, 320, 3, 3, generator=g) / math.sqrt(9 * 320))
+    b = torch.randn(160, generator=g)
+    r = bf(torch.randn(2, 160, 16, 2, generator=g))
+    want = F.conv2d(x, w, b, padding=1) + r
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    for s in (1, 3, 8):
+        y = ops.conv(nhwc(x), pw, pad=(1, 1), res=nhwc(r), splits=s)
+        close(to_nchw(y), want)
+
+
+def test_conv_two_sources_rowbias_residual_f32out(ops):
+    g = torch.Generator().manual_seed(2)
+    x1 = bf(torch.randn(2, 96, 10, 8, generator=g))
+    x2 = bf(torch.randn(2, 64, 10, 8, generator=g))
+    w = bf(torch.randn(96, 160, 3, 3, generator=g) / math.sqrt(9 * 160))
+    b = torch.randn(96, generator=g)
+    temb = torch.randn(2, 300, generator=g)
+    res = bf(torch.randn(2, 96, 10, 8, generator=g))
+    want = F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) + temb[:, 100:196, None, None] + res
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    td = temb.to(DEV)
+    y = ops.conv(nhwc(x1), pw, x2=nhwc(x2), pad=(1, 1), rowbias=td[:, 100:], rowbias_ld=300, res=nhwc(res), out_f32=True)
+    assert y.dtype == torch.float32
+    close(to_nchw(y), want, rtol=2e-3, atol=2e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("ih,iw,uh,uw", [(32, 2, 63, 4), (63, 4, 125, 8), (8, 4, 16, 8)])
+def test_conv_upsample_fold(ops, ih, iw, uh, uw):
+    g = torch.Generator().manual_seed(3)
+    x = bf(torch.randn(2, 64, ih, iw, generator=g))
+    w = bf(torch.randn(64, 64, 3, 3, generator=g) / 24)
+    b = torch.randn(64, generator=g)
+    want = F.conv2d(F.interpolate(x, size=(uh, uw), mode="nearest"), w, b, padding=1)
+    y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), pad=(1, 1), up_size=(uh, uw))
+    assert tuple(y.shape) == (2, uh, uw, 64)
+    close(to_nchw(y), want)
+
+
+@pytest.mark.parametrize("M,K,N,r,tile", [(504, 96, 96, 4, 0), (2000, 256, 256, 8, 1), (130, 160, 160, 16, 2), (64, 640, 640, 4, 0)])
+def test_linear_lora_fused(ops, M, K, N, r, tile):
+    """peft lora.Linear: y = x W^T + b + (alpha/r) (x A^T) B^T, fused in one launch."""
+    g = torch.Generator().manual_seed(4)
+    x = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g)
+    A = bf(torch.randn(r, K, generator=g) / r)
+    Bm = bf(torch.randn(N, r, generator=g) * 0.05)
+    s = 2.0
+    res = bf(torch.randn(M, N, generator=g))
+    want = x @ w.t() + b + s * (x @ A.t()) @ Bm.t() + res
+    pw = ops.pack_linear(w.to(DEV), b.to(DEV))
+    ops.attach_lora(pw, [(0, N, A.to(DEV), Bm.to(DEV), s)])
+    y = ops.linear(x.to(torch.bfloat16).to(DEV), pw, res=res.to(torch.bfloat16).to(DEV), tile=tile)
+    close(y, want)
+    # LoRA with B = 0 must reproduce the base GEMM bit-for-bit
+    pw0 = ops.pack_linear(w.to(DEV), b.to(DEV))
+    y0 = ops.linear(x.to(torch.bfloat16).to(DEV), pw0, tile=tile)
+    ops.attach_lora(pw0, [(0, N, A.to(DEV), torch.zeros_like(Bm).to(DEV), s)])
+    y1 = ops.linear(x.to(torch.bfloat16).to(DEV), pw0, tile=tile)
+    assert torch.equal(y0, y1)
+
+
+def test_qkv_lora_vt_store(ops):
+    g = torch.Generator().manual_seed(5)
+    B, N, Cc, r = 2, 252, 96, 4
+    x = bf(torch.randn(B * N, Cc, generator=g))
+    ws = [bf(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc)) for _ in range(3)]
+    As = [bf(torch.randn(r, Cc, generator=g) / r) for _ in range(3)]
+    Bs = [bf(torch.randn(Cc, r, generator=g) * 0.05) for _ in range(3)]
+    pw = ops.pack_linear(torch.cat(ws).to(DEV), None)
+    ops.attach_lora(pw, [(i * Cc, Cc, As[i].to(DEV), Bs[i].to(DEV), 1.0) for i in (0, 2)])   # q and v only
+    npad = (N + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, npad, dtype=torch.bfloat16, device=DEV)
+    qk = ops.conv(x.to(torch.bfloat16).to(DEV).view(B, 1, N, Cc), pw, vt=vt, vt_col0=2 * Cc, vt_ld=npad,
+                  vt_batch_stride=Cc * npad).view(B * N, 2 * Cc)
+    q = x @ ws[0].t() + (x @ As[0].t()) @ Bs[0].t()
+    k = x @ ws[1].t()
+    v = x @ ws[2].t() + (x @ As[2].t()) @ Bs[2].t()
+    close(qk[:, :Cc], q)
+    close(qk[:, Cc:], k)
+    close(vt[:, :, :N].permute(0, 2, 1).reshape(B * N, Cc), v)
+
+
+def test_geglu(ops):
+    g = torch.Generator().manual_seed(6)
+    M, Cc = 300, 96
+    x = bf(torch.randn(M, Cc, generator=g))
+    w = bf(torch.randn(8 * Cc, Cc, generator=g) / math.sqrt(Cc))
+    b = torch.randn(8 * Cc, generator=g)
+    y = x @ w.t() + b
+    want = y[:, :4 * Cc] * F.gelu(y[:, 4 * Cc:])
+    got = ops.linear(x.to(torch.bfloat16).to(DEV), ops.pack_geglu(w.to(DEV), b.to(DEV)))
+    assert got.shape == (M, 4 * Cc)
+    close(got, want)
+    got2 = ops.linear(x.to(torch.bfloat16).to(DEV), ops.pack_geglu(w.to(DEV), b.to(DEV)), splits=2)
+    close(got2, want)
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,groups,act", [(2, (25, 16), 128, 0, 32, 1), (2, (7, 4), 96, 64, 8, 1), (1, (63, 4), 384, 256, 32, 0), (1, (200, 64), 128, 0, 32, 1)])
+def test_groupnorm(ops, B, HW, C1, C2, groups, act):
+    g = torch.Generator().manual_seed(7)
+    H, W = HW
+    x = bf(torch.randn(B, C1 + C2, H, W, generator=g) * 2 + 0.5)
+    gm, bt = torch.randn(C1 + C2, generator=g), torch.randn(C1 + C2, generator=g)
+    want = F.group_norm(x, groups, gm, bt, eps=1e-5)
+    if act:
+        want = F.silu(want)
+    x1 = nhwc(x[:, :C1])
+    x2 = nhwc(x[:, C1:]) if C2 else None
+    y = ops.groupnorm(x1, gm.to(DEV), bt.to(DEV), groups, 1e-5, act, x2=x2)
+    close(to_nchw(y), want)
+
+
+def test_layernorm(ops):
+    g = torch.Generator().manual_seed(8)
+    for Cc in (64, 96, 256, 640):
+        x = bf(torch.randn(77, Cc, generator=g) * 3 + 1)
+        gm, bt = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+        y = ops.layernorm(x.to(torch.bfloat16).to(DEV), gm.to(DEV), bt.to(DEV))
+        close(y, F.layer_norm(x, (Cc,), gm, bt, 1e-5))
+
+
+@pytest.mark.parametrize("B,N,H,d", [(2, 1000, 8, 32), (2, 252, 8, 48), (2, 64, 8, 80), (1, 1008, 4, 16), (2, 256, 4, 24), (1, 64, 4, 40), (1, 16, 4, 40), (1, 1024, 8, 32)])
+def test_attention(ops, B, N, H, d):
+    g = torch.Generator().manual_seed(9)
+    Cc = H * d
+    q, k, v = (bf(torch.randn(B, N, Cc, generator=g)) for _ in range(3))
+    q = bf(q * 1.5)
+    sp = lambda z: z.view(B, N, H, d).transpose(1, 2)
+    want = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B * N, Cc)
+    qk = torch.cat([q, k], -1).view(B * N, 2 * Cc).to(torch.bfloat16).to(DEV)
+    npad = (N + 7) // 8 * 8
+    vt = torch.full((B, Cc, npad), float("nan"), dtype=torch.bfloat16, device=DEV)   # padding must be ignored
+    vt[:, :, :N] = v.transpose(1, 2).to(torch.bfloat16).to(DEV)
+    out = ops.attention(qk, vt, B, N, H, d)
+    close(out, want, rtol=2e-2, atol=1e-2)
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Force the running max to jump at a late key tile (guide rule 26): spike one key against one query."""
+    g = torch.Generator().manual_seed(10)
+    B, N, H, d = 1, 320, 8, 32
+    Cc = H * d
+    q, k, v = (bf(torch.randn(B, N, Cc, generator=g)) for _ in range(3))
+    k[0, 300] = bf(q[0, 5] * 4.0)          # key 300 (5th tile) dominates query 5's row
+    sp = lambda z: z.view(B, N, H, d).transpose(1, 2)
+    want = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B * N, Cc)
+    qk = torch.cat([q, k], -1).view(B * N, 2 * Cc).to(torch.bfloat16).to(DEV)
+    vt = v.transpose(1, 2).contiguous().to(torch.bfloat16).to(DEV)
+    close(ops.attention(qk, vt, B, N, H, d), want, rtol=2e-2, atol=1e-2)
+
+
+def test_elementwise(ops):
+    g = torch.Generator().manual_seed(11)
+    t = torch.tensor([996.0, 1.0, 501.0])
+    e = ops.timestep_embedding(t.to(DEV), 3, 128)
+    kf = torch.exp(-math.log(10000.0) * torch.arange(64).double() / 64)
+    arg = t.double()[:, None] * kf[None]
+    close(e, torch.cat([arg.cos(), arg.sin()], -1).float(), rtol=1e-2, atol=1e-2)
+    x = torch.randn(2, 8, 5, 4, generator=g)
+    y = ops.nchw_to_nhwc(x.to(DEV))
+    assert torch.equal(y.float().cpu(), bf(x).permute(0, 2, 3, 1))
+    z = ops.nhwc_to_nchw_f32(y)
+    assert torch.equal(z.cpu(), bf(x))
