@@ -82,9 +82,10 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, float* __res
 
 __global__ void advance_step_kernel(int* step_idx, const float* __restrict__ timesteps, int n_steps, float* t_out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const int i = step_idx[0] + 1;
+    int i = step_idx[0] + 1;
+    if (i >= n_steps) i = 0;          // wrap: a replayed graph may run past the schedule (benchmarks)
     step_idx[0] = i;
-    t_out[0] = timesteps[i < n_steps ? i : n_steps - 1];
+    t_out[0] = timesteps[i];
   }
 }
 
@@ -102,6 +103,14 @@ __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict
   const float denom = sqrtf(vv) / bc2_sqrt + eps;
   pv -= (lr / bc1) * (mv / denom);
   p[i] = pv;
+}
+
+__global__ void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ nz, const float* __restrict__ coef,
+                                 int B, long long n, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * n) return;
+  const int b = (int)(idx / n);
+  out[idx] = coef[2 * b] * x[idx] + coef[2 * b + 1] * nz[idx];
 }
 
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -143,6 +152,13 @@ extern "C" int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n
   ALDM_CHECK_ARG(eps && x && coef && step_idx && B > 0 && n_per_sample > 0, "cfg_ddim_step: bad args");
   hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg, guidance, coef, step_idx, (bf16*)x_in_bf16);
   return aldm_launch_status("cfg_ddim_step");
+}
+
+extern "C" int aldm_add_noise(const float* x, const float* noise, const float* coef, int B, long long n_per_sample,
+                              float* out, void* stream) {
+  ALDM_CHECK_ARG(x && noise && coef && out && B > 0 && n_per_sample > 0, "add_noise: bad args");
+  hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x, noise, coef, B, n_per_sample, out);
+  return aldm_launch_status("add_noise");
 }
 
 extern "C" int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream) {

@@ -119,6 +119,36 @@ def auto_splits(M, N, ktiles):
     return max(1, min(8, 384 // tiles, ktiles // 8))
 
 
+def pick_tile(M, N):
+    """Tile heuristic: the widest tile that still yields >= ~1 workgroup per CU (256 CUs)."""
+    t = lambda bm, bn: math.ceil(M / bm) * math.ceil(N / bn)
+    if N <= 64:
+        return _lib.TILE_128x64 if M >= 4096 else _lib.TILE_64x64
+    if t(128, 128) >= 224:
+        return _lib.TILE_128x128
+    if t(128, 64) >= 224:
+        return _lib.TILE_128x64
+    return _lib.TILE_64x64
+
+
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128"}
+
+# Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event).
+# Events are recorded on the stream the kernel is launched on.
+PROFILE = None
+
+
+def _launch(label, flops, nbytes, fn):
+    if PROFILE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn()
+    e.record()
+    PROFILE.append((label, flops, nbytes, s, e))
+    return rc
+
+
 _ws_cache = {}
 
 
@@ -198,8 +228,15 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if splits > 1:
         ws = _workspace(splits * M * pw.N * 4, x.device)
         a.workspace = ws.data_ptr()
+    if tile == 0:
+        tile = pick_tile(M, pw.N)
     a.tile = tile
-    check(_lib.load().aldm_igemm(C.byref(a), _stream()), "aldm_igemm")
+    ktot = KH * KW * pw.Cin
+    flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)
+    nbytes = 2.0 * (B * IH * IW * pw.Cin + pw.N * ktot + M * ncols)
+    label = f"igemm_{TILE_NAMES[tile]}_r{pw.Rp}{'_vt' if vt is not None else ''}{'_sk' if splits > 1 else ''}"
+    lib = _lib.load()
+    check(_launch(label, flops, nbytes, lambda: lib.aldm_igemm(C.byref(a), _stream())), "aldm_igemm")
     return out
 
 
@@ -216,8 +253,10 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
     y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().aldm_groupnorm(_p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y),
-                                     _stream()), "aldm_groupnorm")
+    lib = _lib.load()
+    n = B * H * W * (C1 + C2)
+    check(_launch("groupnorm", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(
+        _p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm")
     return y
 
 
@@ -225,7 +264,9 @@ def layernorm(x2d, gamma, beta, eps=1e-5):
     _require_gpu(x2d)
     M, Cc = x2d.shape
     y = torch.empty_like(x2d)
-    check(_lib.load().aldm_layernorm(_p(x2d), M, Cc, _p(gamma), _p(beta), eps, _p(y), _stream()), "aldm_layernorm")
+    lib = _lib.load()
+    check(_launch("layernorm", 10.0 * M * Cc, 4.0 * M * Cc, lambda: lib.aldm_layernorm(
+        _p(x2d), M, Cc, _p(gamma), _p(beta), eps, _p(y), _stream())), "aldm_layernorm")
     return y
 
 
@@ -237,8 +278,10 @@ def attention(qk, vt, B, N, H, d, out=None):
         out = torch.empty(B * N, Cc, dtype=torch.bfloat16, device=qk.device)
     q_ptr = C.c_void_p(qk.data_ptr())
     k_ptr = C.c_void_p(qk.data_ptr() + Cc * 2)
-    check(_lib.load().aldm_attention(q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N,
-                                     H, d, 1.0 / math.sqrt(d), _p(out), Cc, _stream()), "aldm_attention")
+    lib = _lib.load()
+    check(_launch(f"attention_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention(
+        q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
+        _p(out), Cc, _stream())), "aldm_attention")
     return out
 
 
@@ -288,6 +331,15 @@ def cfg_ddim_step(eps, x, cfg, guidance, coef, step_idx, x_in):
     n = x.numel() // B
     check(_lib.load().aldm_cfg_ddim_step(_p(eps), _p(x), B, n, int(cfg), guidance, _p(coef), _p(step_idx), _p(x_in),
                                          _stream()), "aldm_cfg_ddim_step")
+
+
+def add_noise(x, noise, coef):
+    _require_gpu(x)
+    B = x.shape[0]
+    xf, nf = x.float().contiguous(), noise.float().contiguous()
+    out = torch.empty_like(xf)
+    check(_lib.load().aldm_add_noise(_p(xf), _p(nf), _p(coef), B, xf.numel() // B, _p(out), _stream()), "aldm_add_noise")
+    return out.to(x.dtype)
 
 
 def advance_step(step_idx, timesteps_f32, t_out):

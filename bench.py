@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: UNet denoise-steps/sec (BASELINE.json metric, config[1]).
+
+Workload (config 2 of BASELINE.json / SURVEY.md 8d): cvssp/audioldm-s-full-v2 architecture with random-init
+weights (no checkpoints offline), rank-4 LoRA fused into attention to_q/to_k/to_v/to_out.0, batch 4 prompts
+x 10 s clips => latents [4, 8, 250, 16], classifier-free guidance (UNet batch 8), bf16, DDIM eta = 0.
+A "step" = one denoise step for the whole per-GPU batch: CFG-doubled UNet forward + guidance + scheduler
+step, inputs resident in HBM.  One process per GPU; with N > 1 every rank runs its own prompts (prompt-sharded,
+no collective in the loop -- SURVEY.md 8e), `value` = total steps / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_unet(rank_lora=4, device="cuda"):
+    from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model
+    from audioldm_with_lora_amd.unet import UNet2DConditionModel
+    torch.manual_seed(1234)
+    unet = UNet2DConditionModel()
+    peft = get_peft_model(unet, LoraConfig(r=rank_lora, lora_alpha=rank_lora,
+                                           target_modules=["to_q", "to_k", "to_v", "to_out.0"],
+                                           init_lora_weights="gaussian"))
+    g = torch.Generator().manual_seed(4)
+    for n, p in unet.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.02)     # non-zero, else the adapter is a no-op
+    unet.to(device)
+    return unet, peft
+
+
+def synth_inputs(batch, height, width, seed_off=0):
+    g = torch.Generator().manual_seed(0 + seed_off)
+    lat = torch.randn(batch, 8, height, width, generator=g)
+    pe = torch.nn.functional.normalize(torch.randn(batch, 512, generator=torch.Generator().manual_seed(1 + seed_off)), dim=-1)
+    ne = torch.nn.functional.normalize(torch.randn(batch, 512, generator=torch.Generator().manual_seed(2 + seed_off)), dim=-1)
+    return lat, pe, ne
+
+
+def kernel_profile(engine):
+    """One eager denoise step with an event pair around every launch; returns per-kernel-variant totals."""
+    from audioldm_with_lora_amd import ops
+    ops.PROFILE = []
+    engine._one_step()
+    torch.cuda.synchronize()
+    rows, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for label, flops, nbytes, s, e in rows:
+        a = agg.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a["ms"] += s.elapsed_time(e)
+        a["flops"] += flops
+        a["bytes"] += nbytes
+        a["launches"] += 1
+    return agg
+
+
+def cpu_baseline(batch, height, width, rank_lora, max_seconds=30.0):
+    """The CPU oracle (kind "port": our restatement of the diffusers/peft path) timed on this box's host cores."""
+    from oracle import lora as olora
+    from oracle.unet import UNet2DConditionModel as OracleUNet
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # a 1-GPU box's CPU share is 16 cores; never oversubscribe
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    u = OracleUNet().eval()
+    olora.get_peft_model(u, olora.LoraConfig(r=rank_lora, lora_alpha=rank_lora,
+                                             target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    lat, pe, ne = synth_inputs(batch, height, width)
+    x = torch.cat([lat, lat])
+    emb = torch.cat([ne, pe])
+    times = []
+    with torch.no_grad():
+        t0 = time.time()
+        u(x, torch.tensor(996), class_labels=emb)           # warm-up
+        budget = max_seconds - (time.time() - t0)
+        while len(times) < 3 and (not times or sum(times) + times[-1] < budget):
+            t1 = time.time()
+            eps = u(x, torch.tensor(991), class_labels=emb)[0]
+            eu, et = eps.chunk(2)
+            _ = eu + 2.5 * (et - eu)
+            times.append(time.time() - t1)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "denoise_steps/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} CFG-doubled UNet forwards (b=8, latent {height}x{width}, fp32, rank-{rank_lora} LoRA) "
+                      f"after 1 warm-up; median {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--rank", type=int, default=4)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from audioldm_with_lora_amd.engine import DenoiseEngine
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+
+    H, W, NSTEPS, G = 250, 16, 200, 2.5
+    unet, _ = build_unet(args.rank)
+    eng = DenoiseEngine(unet, DDIMScheduler(), args.batch, H, W, NSTEPS, G, use_graph=not args.no_graph)
+    lat, pe, ne = synth_inputs(args.batch, H, W, seed_off=100 * rank)
+    eng.set_condition(pe, ne)
+    eng.set_latents(lat)
+    eng.capture()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(eng.x).all(), "latents diverged"
+
+    if rank == 0:
+        print(f"[bench] {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
+        prof = kernel_profile(eng)
+        dom_label, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        total_ms = sum(v["ms"] for v in prof.values())
+        if args.breakdown:
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"{k:32s} {v['launches']:4d} launches {v['ms']:8.3f} ms  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:8.1f} TF/s "
+                      f"{v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:8.1f} GB/s", file=sys.stderr)
+            print(f"eager sum {total_ms:.3f} ms over {sum(v['launches'] for v in prof.values())} launches", file=sys.stderr)
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "kernel": dom_label, "launches_per_step": dom["launches"],
+                    "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                    "share_of_step": round(dom["ms"] / total_ms, 3)}
+        out = {
+            "metric": "unet_denoise_steps_per_sec", "value": round(world * args.steps / dt, 3), "unit": "denoise_steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "audioldm-s-full-v2 UNet + rank-%d LoRA (q,k,v,out), DDIM 200-step schedule, "
+                                   "batch %d x 10 s clips (latent 250x16), CFG 2.5 (UNet batch %d), bf16" % (args.rank, args.batch, 2 * args.batch),
+                       "per_gpu_batch": args.batch, "parallelism": f"prompt-sharded x{world}", "hip_graph": not args.no_graph,
+                       "sample_steps_per_sec": round(world * args.steps * args.batch / dt, 2)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch, H, W, args.rank)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -137,8 +137,13 @@ int aldm_f32_to_bf16(const float* x, long long n, float mul, void* y, void* stre
    x (fp32, [B][n]) is updated in place; x_in (bf16, [2B][n] if cfg else [B][n]) receives the next UNet input. */
 int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance,
                        const float* coef, const int* step_idx, void* x_in_bf16, void* stream);
-/* device-side loop counter for graph replay: step_idx[0] += 1 ; t_out[0] = timesteps[min(step_idx, n-1)] */
+/* device-side loop counter for graph replay: step_idx[0] = (step_idx[0] + 1) mod n_steps ; t_out[0] = timesteps[step_idx[0]] */
 int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream);
+
+/* noisy[b][i] = coef[b][0]*x[b][i] + coef[b][1]*noise[b][i]  (DDIMScheduler.add_noise,
+   [REF script/train/train_audioldm_lora.py:504]); fp32 in, fp32 out; coef fp32 [B][2] = {sqrt(abar_t), sqrt(1-abar_t)} */
+int aldm_add_noise(const float* x, const float* noise, const float* coef, int B, long long n_per_sample, float* out,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training helpers (configs 3/4): fused AdamW over one flat fp32 LoRA buffer
