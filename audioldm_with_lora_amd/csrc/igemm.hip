@@ -37,6 +37,7 @@ struct IgemmDev {
   int vt_col0, vt_ld; long long vt_bs;
   int splits, kt_per_split, nkt;
   int tiles_n;
+  unsigned x_bytes, x2_bytes, w_bytes, la_bytes;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -97,6 +98,75 @@ __device__ __forceinline__ void add_bias4(const IgemmDev& p, int m, int n, float
     const float* rb = p.rowbias + (long long)b * p.rowbias_ld;
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += rb[n + j];
+  }
+}
+
+// ---- shared epilogue: acc[MI][NI] 16x16 tiles of one wave -> bias / GEGLU / act / residual / store --------
+template <int MI, int NI, bool VT>
+__device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], const bool (&vt_tile)[NI],
+                                               int wm0, int wn0, int lrow, int lq, int split) {
+  if (p.splits > 1) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = wm0 + i * 16 + lrow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = wn0 + j * 16 + lq * 4;
+        if (n >= p.N) continue;
+        float* o = p.ws + ((long long)split * p.M + m) * p.N + n;
+        *reinterpret_cast<f32x4*>(o) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (VT && vt_tile[j]) {
+        // lane holds 4 consecutive pixels (rows) of channel n: transposed 8-byte store
+        const int n = wn0 + j * 16 + lrow;
+        const int m = wm0 + i * 16 + lq * 4;
+        if (n >= p.N || m >= p.M) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const float bb = p.bias ? p.bias[n] : 0.f;
+        const int b = m / p.OHW, pix = m - b * p.OHW;
+        bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
+        if (m + 3 < p.M && pix + 3 < p.OHW && ((p.vt_ld & 3) == 0) && ((pix & 3) == 0)) {
+          *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16)(v[0] + bb), (bf16)(v[1] + bb), (bf16)(v[2] + bb), (bf16)(v[3] + bb)};
+        } else {
+          for (int q = 0; q < 4; ++q) {
+            const int mq = m + q;
+            if (mq >= p.M) break;
+            const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
+            p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(v[q] + bb);
+          }
+        }
+        continue;
+      }
+      const int m = wm0 + i * 16 + lrow;
+      const int n = wn0 + j * 16 + lq * 4;
+      if (m >= p.M || n >= p.N) continue;
+      if (p.geglu) {
+        if (j & 1) continue;  // gate tile is consumed together with its value tile
+        float val[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const int jg = (j + 1 < NI) ? j + 1 : j;
+        float gate[4] = {acc[i][jg][0], acc[i][jg][1], acc[i][jg][2], acc[i][jg][3]};
+        if (p.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { val[q] += p.bias[n + q]; gate[q] += p.bias[n + 16 + q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] *= gelu_erf_f(gate[q]);
+        const int nout = ((n >> 5) << 4) + (n & 15);
+        finish_store4(p, m, nout, p.N >> 1, val);
+      } else {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        add_bias4(p, m, n, v);
+        finish_store4(p, m, n, p.N, v);
+      }
+    }
   }
 }
 
@@ -291,9 +361,10 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
         if (p.lora_t_out && tile_n == 0 && m0 + r < p.M)
           *reinterpret_cast<bf16x4*>(p.lora_t_out + ((long long)split * p.M + m0 + r) * RP + col) = tv;
       }
-    constexpr int LB_CHUNKS = BN * (RP / 8);
+    constexpr int RCH = RP > 0 ? RP / 8 : 1;
+    constexpr int LB_CHUNKS = BN * RCH;
     for (int c = tid; c < LB_CHUNKS; c += THREADS) {
-      const int r = c / (RP / 8), ch = c - r * (RP / 8);
+      const int r = c / RCH, ch = c - r * RCH;
       const int n = n0 + r;
       bf16x8 v = zero8;
       if (n < p.N) v = *reinterpret_cast<const bf16x8*>(p.lora_b + (long long)n * RP + ch * 8);
@@ -304,71 +375,249 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
     for (int ks = 0; ks < RP / 32; ++ks) mma_step(0, ks, false);
   }
 
-  // ---- epilogue ----
-  const int wm0 = m0 + wm * (BM / WM), wn0 = n0 + wn * (BN / WN);
-  if (p.splits > 1) {
+  igemm_epilogue<MI, NI, VT>(p, acc, vt_tile, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lrow, lq, split);
+}
+
+// ---- pipelined kernel: LDS-DMA (buffer_load ... lds) ring, counted vmcnt, one raw barrier per K-tile -------
+// The register-staged kernel above exposes a full HBM/L2 round trip per K-tile and spends hundreds of VALU
+// instructions per K-tile on gather addresses.  Here every 16-byte chunk of the activation gather and of the
+// weight tile goes global -> LDS directly (no VGPR staging) into an S-deep ring, S-1 K-tiles ahead of the
+// MFMAs; the only waits in the loop are a COUNTED s_waitcnt vmcnt((S-2)*L) and one s_barrier.
+//   * Requires Cin % 64 == 0 (and Cin2 % 64 == 0): a K-tile then lies inside ONE filter tap of ONE source, so
+//     the tap / source / channel cursor is SCALAR.  Per-lane byte offsets (pixel * C + chunk) are recomputed
+//     only when the tap or source changes; the channel advance inside a tap rides in the instruction's
+//     scalar offset, so steady-state K-tiles cost one buffer_load per 16-byte chunk and nothing else.
+//   * Zero padding uses the buffer descriptor's range check: padded taps get voffset 0x80000000 and the DMA
+//     writes zeros.  Rows past M / N are clamped (their results are never stored).
+//   * The LDS image is the same XOR-swizzled [row][64] layout: the DMA writes lane-linear, so the swizzle is
+//     applied to the per-lane SOURCE chunk instead (both-sides-or-neither).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+#endif
+
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
+__global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int BROWS = BN + RP;
+  constexpr int A_PASSES = BM / 32, W_PASSES = BN / 32, B_PASSES = BROWS / 32;
+  constexpr int L = A_PASSES + B_PASSES;   // LDS-DMA instructions per thread per K-tile
+  constexpr int D = S - 1;                 // K-tiles in flight ahead of the MFMAs
+  constexpr int STAGE = (BM + BROWS) * 128;
+  constexpr int RT_W = RP / 16 / WN;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert((D - 1) * L < 64, "vmcnt immediate");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [S][ A: BM x 128 B | B: BROWS x 128 B ]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int kt0 = split * p.kt_per_split;
+  const int kt1 = min(p.nkt, kt0 + p.kt_per_split);
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? (const void*)p.x2 : (const void*)p.x, p.x2 ? p.x2_bytes : p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+  const __amdgpu_buffer_rsrc_t rs_la = make_rsrc(RP > 0 ? (const void*)p.lora_a : (const void*)p.w, RP > 0 ? p.la_bytes : p.w_bytes);
+
+  // this lane DMA-writes physical chunk (tid & 7) of row (tid >> 3) + 32*pass; the logical (source) chunk is
+  // the swizzle's inverse image (the XOR is an involution and depends on (row >> 1) & 7 only, not on pass)
+  const int rbase = tid >> 3;
+  const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);
+  int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < A_PASSES; ++ps) {
+    const int m = min(m0 + rbase + 32 * ps, p.M - 1);
+    const int b = m / p.OHW;
+    const int pix = m - b * p.OHW;
+    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    a_pix0[ps] = b * p.IH * p.IW;
+    a_ih0[ps] = oh * p.sh - p.ph;
+    a_iw0[ps] = ow * p.sw - p.pw;
+  }
+  unsigned b_off[B_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < B_PASSES; ++ps) {
+    const int r = rbase + 32 * ps;
+    const int row = ps < W_PASSES ? min(n0 + r, p.N - 1) : r - BN;
+    b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
+  }
+  // scalar K cursor
+  int s_kh, s_kw, s_c0;
+  {
+    const int k = kt0 * BK;
+    const int tap = k / p.Ctot;
+    s_c0 = k - tap * p.Ctot;
+    s_kh = tap / p.KW;
+    s_kw = tap - s_kh * p.KW;
+  }
+  bool s_fresh = true;     // tap or source changed: per-lane offsets must be recomputed
+  unsigned cur_off[A_PASSES];
+  int a_soff = 0, b_soff = kt0 * BK * 2;
+  const int IHv = p.UH > 0 ? p.UH : p.IH, IWv = p.UW > 0 ? p.UW : p.IW;
+
+  auto issue = [&](int kt, int stage) {
+    char* sbase = smem + stage * STAGE + wave * 1024;   // + pass * 4096: this wave's 8 rows of the pass
+    const bool live = kt < kt1;
+    const bool src2 = s_c0 >= p.Cin;
+    if (live) {
+      if (s_fresh) {
+        const int Cs = src2 ? p.Cin2 : p.Cin;
+        const int dh = s_kh * p.dh, dw = s_kw * p.dw;
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+          int ih = a_ih0[ps] + dh, iw = a_iw0[ps] + dw;
+          const bool ok = (unsigned)ih < (unsigned)IHv && (unsigned)iw < (unsigned)IWv;
+          if (p.UH > 0) {
+            if (p.UH == 2 * p.IH) ih >>= 1; else ih = (ih * p.IH) / p.UH;
+            if (p.UW == 2 * p.IW) iw >>= 1; else iw = (iw * p.IW) / p.UW;
+          }
+          const unsigned off = (unsigned)(a_pix0[ps] + ih * p.IW + iw) * (unsigned)(Cs * 2) + kchunk * 16;
+          cur_off[ps] = ok ? off : OOB;
+        }
+        s_fresh = false;
+      }
+      a_soff = (s_c0 - (src2 ? p.Cin : 0)) * 2;
+      b_soff = kt * BK * 2;
+    }
+    if (src2) {
+#pragma unroll
+      for (int ps = 0; ps < A_PASSES; ++ps)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * 4096), 16, cur_off[ps], a_soff, 0, 0);
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < A_PASSES; ++ps)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + ps * 4096), 16, cur_off[ps], a_soff, 0, 0);
+    }
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+      if (ps < W_PASSES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * 128 + ps * 4096), 16, b_off[ps], b_soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_la, (lds_ptr_t)(sbase + BM * 128 + ps * 4096), 16, b_off[ps], b_soff, 0, 0);
+    }
+    if (live) {   // advance the scalar cursor by one K-tile
+      s_c0 += BK;
+      if (s_c0 == p.Cin && p.Cin2 > 0) s_fresh = true;
+      if (s_c0 >= p.Ctot) {
+        s_c0 = 0;
+        s_fresh = true;
+        if (++s_kw == p.KW) { s_kw = 0; ++s_kh; }
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 tacc[MI][RT_W > 0 ? RT_W : 1];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < (RT_W > 0 ? RT_W : 1); ++j) tacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool vt_tile[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) vt_tile[j] = VT && (n0 + wn * (BN / WN) + j * 16 >= p.vt_col0);
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  auto mma_step = [&](int stage, int ks, bool with_t) {
+    const char* As = smem + stage * STAGE;
+    const char* Bs = As + BM * 128;
+    const int ch = ks * 4 + lq;
+    bf16x8 af[MI], wf[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int m = wm0 + i * 16 + lrow;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = wn0 + j * 16 + lq * 4;
-        if (n >= p.N) continue;
-        float* o = p.ws + ((long long)split * p.M + m) * p.N + n;
-        *reinterpret_cast<f32x4*>(o) = acc[i][j];
-      }
+      const int r = wm * (BM / WM) + i * 16 + lrow;
+      af[i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + swz(r, ch) * 16);
     }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      if (VT && vt_tile[j]) {
-        // lane holds 4 consecutive pixels (rows) of channel n: transposed 8-byte store
-        const int n = wn0 + j * 16 + lrow;
-        const int m = wm0 + i * 16 + lq * 4;
-        if (n >= p.N || m >= p.M) continue;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        const float bb = p.bias ? p.bias[n] : 0.f;
-        const int b = m / p.OHW, pix = m - b * p.OHW;
-        bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
-        if (m + 3 < p.M && pix + 3 < p.OHW && ((p.vt_ld & 3) == 0) && ((pix & 3) == 0)) {
-          *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16)(v[0] + bb), (bf16)(v[1] + bb), (bf16)(v[2] + bb), (bf16)(v[3] + bb)};
-        } else {
-          for (int q = 0; q < 4; ++q) {
-            const int mq = m + q;
-            if (mq >= p.M) break;
-            const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
-            p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(v[q] + bb);
-          }
-        }
-        continue;
+      const int r = wn * (BN / WN) + j * 16 + lrow;
+      wf[j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + swz(r, ch) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (VT && vt_tile[j])
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
-      const int m = wm0 + i * 16 + lrow;
-      const int n = wn0 + j * 16 + lq * 4;
-      if (m >= p.M || n >= p.N) continue;
-      if (p.geglu) {
-        if (j & 1) continue;  // gate tile is consumed together with its value tile
-        float val[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        const int jg = (j + 1 < NI) ? j + 1 : j;
-        float gate[4] = {acc[i][jg][0], acc[i][jg][1], acc[i][jg][2], acc[i][jg][3]};
-        if (p.bias) {
+    if (RP > 0 && with_t) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { val[q] += p.bias[n + q]; gate[q] += p.bias[n + 16 + q]; }
-        }
+      for (int t = 0; t < RT_W; ++t) {
+        const int r = BN + (wn * RT_W + t) * 16 + lrow;
+        const bf16x8 lf = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + swz(r, ch) * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) val[q] *= gelu_erf_f(gate[q]);
-        const int nout = ((n >> 5) << 4) + (n & 15);
-        finish_store4(p, m, nout, p.N >> 1, val);
-      } else {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        add_bias4(p, m, n, v);
-        finish_store4(p, m, n, p.N, v);
+        for (int i = 0; i < MI; ++i)
+          tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[i], tacc[i][t], 0, 0, 0);
       }
     }
+  };
+
+  // ---- ring: prologue fills D stages; steady state = wait(tile kt landed) -> barrier -> refill the stage
+  //      freed by tile kt-1 -> MFMAs on tile kt.  Tiles past the end are dummy zero-page loads so that the
+  //      vmcnt immediate stays constant.
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(kt0 + s, s);
+  int st = 0, st_fill = D;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    wait_vmcnt<(D - 1) * L>();
+    __builtin_amdgcn_s_barrier();
+    issue(kt + D, st_fill);
+    mma_step(st, 0, true);
+    mma_step(st, 1, true);
+    st = (st + 1 == S) ? 0 : st + 1;
+    st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
   }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // ---- LoRA: T (bf16) -> LDS stage 0, then one more K-step against the pre-scaled B ----
+  if (RP > 0) {
+    char* As = smem;
+    char* Bs = smem + BM * 128;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int t = 0; t < RT_W; ++t) {
+        const int r = wm * (BM / WM) + i * 16 + lrow;
+        const int col = (wn * RT_W + t) * 16 + lq * 4;
+        bf16x4 tv = {(bf16)tacc[i][t][0], (bf16)tacc[i][t][1], (bf16)tacc[i][t][2], (bf16)tacc[i][t][3]};
+        *reinterpret_cast<bf16x4*>(As + r * 128 + swz(r, col >> 3) * 16 + (col & 7) * 2) = tv;
+        if (p.lora_t_out && tile_n == 0 && m0 + r < p.M)
+          *reinterpret_cast<bf16x4*>(p.lora_t_out + ((long long)split * p.M + m0 + r) * RP + col) = tv;
+      }
+    constexpr int RCH = RP > 0 ? RP / 8 : 1;
+    constexpr int LB_CHUNKS = BN * RCH;
+    for (int c = tid; c < LB_CHUNKS; c += THREADS) {
+      const int r = c / RCH, ch = c - r * RCH;
+      const int n = n0 + r;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (n < p.N) v = *reinterpret_cast<const bf16x8*>(p.lora_b + (long long)n * RP + ch * 8);
+      *reinterpret_cast<bf16x8*>(Bs + r * 128 + swz(r, ch) * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < RP / 32; ++ks) mma_step(0, ks, false);
+  }
+  igemm_epilogue<MI, NI, VT>(p, acc, vt_tile, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lrow, lq, split);
+#endif
 }
 
 // ---- split-K reduce + epilogue ----------------------------------------------------------------
@@ -408,11 +657,14 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int RP, bool VT>
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
 int launch_cfg(const IgemmDev& d, hipStream_t st) {
-  constexpr size_t lds = 2 * (size_t)(BM + BN + RP) * 128;
+  // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
+  constexpr size_t lds = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128;
   static bool attr_done = false;   // one-time, idempotent; races are benign
-  auto kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
+  void (*kern)(const IgemmDev);
+  if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
+  else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { aldm_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -425,16 +677,26 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   return aldm_launch_status("igemm");
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_tile(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int S>
+int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
   if (vt) {
-    if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true>(d, st);
-    if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true>(d, st);
-    return launch_cfg<BM, BN, WM, WN, 64, true>(d, st);
+    if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S>(d, st);
+    if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S>(d, st);
+    return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
   }
-  if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false>(d, st);
-  if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false>(d, st);
-  return launch_cfg<BM, BN, WM, WN, 64, false>(d, st);
+  if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S>(d, st);
+  if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S>(d, st);
+  return launch_cfg<BM, BN, WM, WN, 64, false, S>(d, st);
+}
+
+template <int BM, int BN, int WM, int WN, int S>
+int launch_tile(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
+  // LDS-DMA ring needs a scalar K cursor (64-channel K-tiles inside one tap of one source), no gather-side
+  // activation and < 2 GiB activations (32-bit buffer offsets, 0x80000000 = "padded tap").
+  const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u &&
+                    d.x2_bytes < 0x80000000u;
+  if (!fast) return launch_rp<BM, BN, WM, WN, 0>(d, Rp, vt, st);
+  return launch_rp<BM, BN, WM, WN, S>(d, Rp, vt, st);
 }
 
 int pick_tile(int M, int N) {
@@ -490,16 +752,25 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   d.kt_per_split = cdiv(d.nkt, d.splits);
   d.splits = cdiv(d.nkt, d.kt_per_split);
   d.tiles_n = 0;
+  {
+    const unsigned long long xb = 2ull * p->B * p->IH * p->IW * p->Cin, x2b = 2ull * p->B * p->IH * p->IW * p->Cin2;
+    const unsigned long long wb = 2ull * p->Cout * p->Kpad, lb = 2ull * p->Rp * p->Kpad;
+    ALDM_CHECK_ARG(wb < 0xFFFFFFFFull, "igemm: weight matrix too large for 32-bit offsets");
+    d.x_bytes = xb < 0xFFFFFFFFull ? (unsigned)xb : 0xFFFFFFFFu;
+    d.x2_bytes = x2b < 0xFFFFFFFFull ? (unsigned)x2b : 0xFFFFFFFFu;
+    d.w_bytes = (unsigned)wb;
+    d.la_bytes = (unsigned)lb;
+  }
   hipStream_t st = (hipStream_t)stream;
 
   int tile = p->tile ? p->tile : pick_tile(d.M, d.N);
   const bool vt = p->vt != nullptr;
   int rc;
   switch (tile) {
-    case ALDM_TILE_128x128: rc = launch_tile<128, 128, 2, 2>(d, p->Rp, vt, st); break;
-    case ALDM_TILE_128x64: rc = launch_tile<128, 64, 2, 2>(d, p->Rp, vt, st); break;
-    case ALDM_TILE_64x128: rc = launch_tile<64, 128, 2, 2>(d, p->Rp, vt, st); break;
-    case ALDM_TILE_64x64: rc = launch_tile<64, 64, 2, 2>(d, p->Rp, vt, st); break;
+    case ALDM_TILE_128x128: rc = launch_tile<128, 128, 2, 2, 3>(d, p->Rp, vt, st); break;
+    case ALDM_TILE_128x64: rc = launch_tile<128, 64, 2, 2, 3>(d, p->Rp, vt, st); break;
+    case ALDM_TILE_64x128: rc = launch_tile<64, 128, 2, 2, 3>(d, p->Rp, vt, st); break;
+    case ALDM_TILE_64x64: rc = launch_tile<64, 64, 2, 2, 4>(d, p->Rp, vt, st); break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;
   }
   if (rc != ALDM_OK) return rc;

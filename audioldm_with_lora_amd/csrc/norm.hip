@@ -36,7 +36,10 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __res
 
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;  // quads per pixel in this group
-  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  // batch-minor block order: the 32 group-workgroups of one image then share an XCD (blocks b, b+8, ... land on
+  // the same L2), so each 128-byte line of the image is fetched into ONE L2 instead of eight.
+  const int nb = gridDim.x / groups;
+  const int g = blockIdx.x / nb, b = blockIdx.x - g * nb;
   const int c0 = g * Cg;
   const int nquads = HW * qpp;
   const bool cached = nquads <= GN_LDS_QUADS;

@@ -112,21 +112,20 @@ def attach_lora(pw: PackedW, parts):
 
 
 def auto_splits(M, N, ktiles):
-    """Split-K heuristic for the low-resolution UNet levels (few output tiles, deep K)."""
+    """Split-K heuristic (tools/bench_igemm.py sweep): the low-resolution UNet levels have few 64x64 output
+    tiles but deep K; split until ~512 workgroups are in flight, at most 4 ways, >= 8 K-tiles per split."""
     tiles = math.ceil(M / 64) * math.ceil(N / 64)
-    if tiles >= 160 or ktiles < 16:
+    if tiles >= 256 or ktiles < 16:
         return 1
-    return max(1, min(8, 384 // tiles, ktiles // 8))
+    return max(1, min(4, math.ceil(512 / tiles), ktiles // 8))
 
 
 def pick_tile(M, N):
-    """Tile heuristic: the widest tile that still yields >= ~1 workgroup per CU (256 CUs)."""
-    t = lambda bm, bn: math.ceil(M / bm) * math.ceil(N / bn)
-    if N <= 64:
-        return _lib.TILE_128x64 if M >= 4096 else _lib.TILE_64x64
-    if t(128, 128) >= 224:
-        return _lib.TILE_128x128
-    if t(128, 64) >= 224:
+    """Tile heuristic from tools/bench_igemm.py sweeps on MI355X: 128x64 once it still yields >= ~2 workgroups
+    per CU (256 CUs), else 64x64 (more, smaller workgroups hide the short K loops of the low-res levels)."""
+    if N > 64 and math.ceil(M / 128) * math.ceil(N / 64) >= 448:
+        return _lib.TILE_128x64
+    if N <= 64 and M >= 4096:
         return _lib.TILE_128x64
     return _lib.TILE_64x64
 
