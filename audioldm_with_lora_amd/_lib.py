@@ -34,6 +34,7 @@ class IgemmArgs(C.Structure):
         ("out_act", C.c_int), ("out_slope", C.c_float),
         ("res", C.c_void_p), ("res2", C.c_void_p),
         ("alpha", C.c_float),
+        ("post_act", C.c_int), ("post_slope", C.c_float), ("out2", C.c_void_p),
         ("out", C.c_void_p), ("out_dtype", C.c_int), ("out_ld", C.c_int),
         ("out_batch_stride", C.c_longlong),
         ("out_pix_stride", C.c_int), ("out_pix_offset", C.c_int),

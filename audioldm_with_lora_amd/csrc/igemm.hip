@@ -33,6 +33,7 @@ struct IgemmDev {
   int OH, OW, OHW, N, M, Kpad;
   int in_act; float in_slope;
   int rowbias_ld, geglu, out_act; float out_slope; float alpha;
+  int post_act; float post_slope; bf16* out2;
   int out_f32, out_ld; long long out_bs; int out_ps, out_po;
   int vt_col0, vt_ld; long long vt_bs;
   int splits, kt_per_split, nkt;
@@ -48,7 +49,7 @@ __device__ __forceinline__ void finish_store4(const IgemmDev& p, int m, int n, i
   const int b = m / p.OHW;
   const int pix = m - b * p.OHW;
   const long long row = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
-  const bool vec = (n + 3 < ncols) && ((p.out_ld & 3) == 0);
+  const bool vec = (n + 3 < ncols) && ((p.out_ld & 3) == 0) && ((p.out_bs & 3) == 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.out_act, p.out_slope);
   if (p.res) {
@@ -70,6 +71,18 @@ __device__ __forceinline__ void finish_store4(const IgemmDev& p, int m, int n, i
     } else {
       for (int j = 0; j < 4; ++j) if (n + j < ncols) v[j] += (float)p.res2[row + n + j];
     }
+  }
+  if (p.out2) {
+    bf16* o2 = p.out2 + row + n;
+    if (vec) {
+      *reinterpret_cast<bf16x4*>(o2) = bf16x4{(bf16)apply_act(v[0], p.post_act, p.post_slope), (bf16)apply_act(v[1], p.post_act, p.post_slope),
+                                              (bf16)apply_act(v[2], p.post_act, p.post_slope), (bf16)apply_act(v[3], p.post_act, p.post_slope)};
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < ncols) o2[j] = (bf16)apply_act(v[j], p.post_act, p.post_slope);
+    }
+  } else if (p.post_act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.post_act, p.post_slope);
   }
   if (p.out_f32) {
     float* o = reinterpret_cast<float*>(p.out) + row + n;
@@ -728,6 +741,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(p->Rp == 0 || (p->lora_a && p->lora_b), "igemm: Rp without lora_a/lora_b");
   ALDM_CHECK_ARG(!p->geglu || (p->Cout % 32 == 0 && !p->rowbias), "igemm: GEGLU needs Cout %% 32 == 0");
   ALDM_CHECK_ARG(!p->vt || (p->vt_col0 % 16 == 0 && p->splits <= 1 && !p->geglu), "igemm: bad vt config");
+  ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
 
@@ -743,6 +757,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   d.in_act = p->in_act; d.in_slope = p->in_slope;
   d.rowbias_ld = p->rowbias_ld; d.geglu = p->geglu; d.out_act = p->out_act; d.out_slope = p->out_slope;
   d.alpha = p->alpha;
+  d.post_act = p->post_act; d.post_slope = p->post_slope; d.out2 = (bf16*)p->out2;
   d.out_f32 = p->out_dtype == ALDM_OUT_F32; d.out_ld = p->out_ld;
   d.out_bs = p->out_batch_stride; d.out_ps = p->out_pix_stride > 0 ? p->out_pix_stride : 1; d.out_po = p->out_pix_offset;
   d.vt_col0 = p->vt_col0; d.vt_ld = p->vt_ld; d.vt_bs = p->vt_batch_stride;

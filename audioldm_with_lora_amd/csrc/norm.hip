@@ -85,6 +85,71 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __res
   }
 }
 
+// Register-resident variant for strips of <= 512*QPT quads (every UNet site): all loads are issued up front
+// (QPT independent 8-byte loads in flight per thread), the strip never leaves registers, two block reductions.
+template <int QPT>
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x2,
+                                                                   int HW, int C1, int C2, int groups, float eps,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, int act,
+                                                                   bf16* __restrict__ y) {
+  __shared__ float red[GN_THREADS / 64];
+  const int C = C1 + C2;
+  const int Cg = C / groups, qpp = Cg >> 2;
+  const int nb = gridDim.x / groups;
+  const int g = blockIdx.x / nb, b = blockIdx.x - g * nb;   // batch-minor: one image's groups share an XCD's L2
+  const int c0 = g * Cg;
+  const int nquads = HW * qpp;
+  const int tid = threadIdx.x;
+
+  bf16x4 v[QPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + i * GN_THREADS;
+    bf16x4 t = {0, 0, 0, 0};
+    if (q < nquads) {
+      const int pix = q / qpp, j = q - pix * qpp;
+      const int c = c0 + 4 * j;
+      t = (c < C1) ? *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c)
+                   : *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
+    }
+    v[i] = t;
+  }
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) s += (float)v[i][0] + (float)v[i][1] + (float)v[i][2] + (float)v[i][3];
+  const float n = (float)nquads * 4.f;
+  const float mean = block_sum(s, red, tid, GN_THREADS) / n;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (tid + i * GN_THREADS < nquads) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = (float)v[i][k] - mean; ss += d * d; }
+    }
+  }
+  const float var = block_sum(ss, red, tid, GN_THREADS) / n;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + i * GN_THREADS;
+    if (q < nquads) {
+      const int pix = q / qpp, j = q - pix * qpp;
+      const int c = c0 + 4 * j;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+      bf16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = ((float)v[i][k] - mean) * (gm[k] * rstd) + bt[k];
+        if (act == ALDM_ACT_SILU) t = silu_f(t);
+        o[k] = (bf16)t;
+      }
+      *reinterpret_cast<bf16x4*>(y + ((long long)b * HW + pix) * C + c) = o;
+    }
+  }
+}
+
 // LayerNorm: one wave per row, 16-byte chunks, C <= 64*8*MAXC.
 constexpr int LN_MAXC = 4;  // chunks per lane -> C <= 2048
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int M, int C,
@@ -150,8 +215,18 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
     if (e != hipSuccess) { aldm_set_error("groupnorm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16*)x,
-                     (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y);
+  const long long nquads = (long long)HW * (C / groups / 4);
+#define ALDM_GN_REG(QPT)                                                                                               \
+  hipLaunchKernelGGL(groupnorm_reg_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
+                     (const bf16*)x, (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y)
+  if (nquads <= 4 * GN_THREADS) ALDM_GN_REG(4);
+  else if (nquads <= 8 * GN_THREADS) ALDM_GN_REG(8);
+  else if (nquads <= 16 * GN_THREADS) ALDM_GN_REG(16);
+  else if (nquads <= 32 * GN_THREADS) ALDM_GN_REG(32);
+  else
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y);
+#undef ALDM_GN_REG
   return aldm_launch_status("groupnorm");
 }
 

@@ -162,7 +162,7 @@ def _workspace(nbytes, device):
 
 def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, stride=(1, 1), pad=(0, 0), dil=(1, 1),
          up_size=None, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
-         out_slope=0.0, res=None, res2=None, alpha=1.0, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
+         out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
          splits=None, tile=0):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2])."""
@@ -214,6 +214,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     a.res = res.data_ptr() if res is not None else None
     a.res2 = res2.data_ptr() if res2 is not None else None
     a.alpha = alpha
+    a.post_act, a.post_slope = post_act, post_slope
+    a.out2 = out2.data_ptr() if out2 is not None else None
     a.out, a.out_dtype, a.out_ld = out.data_ptr(), (OUT_F32 if out.dtype == torch.float32 else OUT_BF16), out_ld
     a.out_batch_stride = out_batch_stride
     a.out_pix_stride, a.out_pix_offset = out_pix_stride, out_pix_offset

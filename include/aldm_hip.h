@@ -65,7 +65,8 @@ typedef struct {
   int Rp;                   /* 0, 32 or 64 */
   void* lora_t_out;         /* optional [M][Rp] bf16 copy of T (training saves it) */
   /* epilogue: v = acc + bias[n] + rowbias[b][n];  GEGLU (optional);  v = out_act(v);
-     v = alpha*(v + res) + res2;  store                                              */
+     v = alpha*(v + res) + res2;  out = v;  out2 = post_act(v) (if out2) -- or out = post_act(v) when
+     post_act is set without out2 (HiFi-GAN: residual stream + its leaky-relu'd copy in one pass)   */
   const float* bias;        /* [Cout] fp32 or null */
   const float* rowbias;     /* [B][rowbias_ld] fp32 or null (time-embedding projection) */
   int rowbias_ld;
@@ -73,6 +74,7 @@ typedef struct {
   int out_act;  float out_slope;
   const void* res;  const void* res2;   /* bf16, addressed exactly like out */
   float alpha;
+  int post_act;  float post_slope;  void* out2;     /* out2: bf16, addressed exactly like out */
   void* out;  int out_dtype;  int out_ld;           /* columns per output row */
   long long out_batch_stride;                       /* elements between batches */
   int out_pix_stride, out_pix_offset;               /* row = pix*stride + offset (conv_transpose phases) */
