@@ -1,0 +1,733 @@
+// Implicit-GEMM convolution / linear on gfx950 MFMA (bf16 x bf16 -> fp32), with fused LoRA
+// side channel, GEGLU, bias / time-embedding / residual epilogues, transposed V^T store and split-K.
+//
+// Serves every F.conv2d / F.linear / conv1d / conv_transpose1d phase and peft lora.Linear under
+// UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546], AutoencoderKL.decode
+// and SpeechT5HifiGan.forward [REF script/inference/generate_audio.py:47-52].
+//
+// Structure (MI355X-first, not a CUDA tiling):
+//   * workgroup = 4 wave64s in a WM x WN grid; each wave owns a (BM/WM) x (BN/WN) output block built from
+//     v_mfma_f32_16x16x32_bf16 tiles.  The MFMA is issued "swapped" (weights as the A operand) so each
+//     lane ends up with 4 CONSECUTIVE output channels of one pixel -> 8-byte epilogue stores.
+//   * K-tile = 64 channels of one filter tap.  The activation tile is gathered (NHWC, zero padding,
+//     optional nearest-upsample index map, optional second source = virtual channel concat) straight
+//     into registers as 16-byte chunks and written to an XOR-swizzled LDS image so that every
+//     ds_read_b128 fragment read is bank-conflict free; double-buffered, one barrier per K-tile.
+//   * LoRA: the rank-r projection T = X A^T rides along the main K loop as extra MFMA columns
+//     (the LoRA-A rows are appended to the weight tile); T is then converted to bf16 in LDS and
+//     consumed as one more K-step against (alpha/r) B -- no extra launch, no extra pass over X.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace aldm_igemm_detail {
+
+constexpr int BK = 64;
+constexpr int THREADS = 256;
+
+struct IgemmDev {
+  const bf16* x; const bf16* x2; const bf16* w; const bf16* lora_a; const bf16* lora_b;
+  bf16* lora_t_out;
+  const float* bias; const float* rowbias; const bf16* res; const bf16* res2;
+  void* out; bf16* vt; float* ws;
+  int B, IH, IW, Cin, Cin2, Ctot, UH, UW;
+  int KH, KW, sh, sw, ph, pw, dh, dw;
+  int OH, OW, OHW, N, M, Kpad;
+  int in_act; float in_slope;
+  int rowbias_ld, geglu, out_act; float out_slope; float alpha;
+  int post_act; float post_slope; bf16* out2;
+  int out_f32, out_ld; long long out_bs; int out_ps, out_po;
+  int vt_col0, vt_ld; long long vt_bs;
+  int splits, kt_per_split, nkt;
+  int tiles_n;
+  unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ---- epilogue helpers -------------------------------------------------------------------------
+// v[0..3] are 4 consecutive output columns n..n+3 of output row m, bias etc. already added.
+__device__ __forceinline__ void finish_store4(const IgemmDev& p, int m, int n, int ncols, float* v) {
+  const int b = m / p.OHW;
+  const int pix = m - b * p.OHW;
+  const long long row = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
+  const bool vec = (n + 3 < ncols) && ((p.out_ld & 3) == 0) && ((p.out_bs & 3) == 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.out_act, p.out_slope);
+  if (p.res) {
+    if (vec) {
+      bf16x4 r = *reinterpret_cast<const bf16x4*>(p.res + row + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < ncols) v[j] += (float)p.res[row + n + j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+  if (p.res2) {
+    if (vec) {
+      bf16x4 r = *reinterpret_cast<const bf16x4*>(p.res2 + row + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < ncols) v[j] += (float)p.res2[row + n + j];
+    }
+  }
+  if (p.out2) {
+    bf16* o2 = p.out2 + row + n;
+    if (vec) {
+      *reinterpret_cast<bf16x4*>(o2) = bf16x4{(bf16)apply_act(v[0], p.post_act, p.post_slope), (bf16)apply_act(v[1], p.post_act, p.post_slope),
+                                              (bf16)apply_act(v[2], p.post_act, p.post_slope), (bf16)apply_act(v[3], p.post_act, p.post_slope)};
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < ncols) o2[j] = (bf16)apply_act(v[j], p.post_act, p.post_slope);
+    }
+  } else if (p.post_act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.post_act, p.post_slope);
+  }
+  if (p.out_f32) {
+    float* o = reinterpret_cast<float*>(p.out) + row + n;
+    if (vec) {
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < ncols) o[j] = v[j];
+    }
+  } else {
+    bf16* o = reinterpret_cast<bf16*>(p.out) + row + n;
+    if (vec) {
+      *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    } else {
+      for (int j = 0; j < 4; ++j) if (n + j < ncols) o[j] = (bf16)v[j];
+    }
+  }
+}
+
+__device__ __forceinline__ void add_bias4(const IgemmDev& p, int m, int n, float* v) {
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += p.bias[n + j];
+  }
+  if (p.rowbias) {
+    const int b = m / p.OHW;
+    const float* rb = p.rowbias + (long long)b * p.rowbias_ld;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += rb[n + j];
+  }
+}
+
+// ---- shared epilogue: acc[MI][NI] 16x16 tiles of one wave -> bias / GEGLU / act / residual / store --------
+template <int MI, int NI, bool VT>
+__device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], const bool (&vt_tile)[NI],
+                                               int wm0, int wn0, int lrow, int lq, int split) {
+  if (p.splits > 1) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = wm0 + i * 16 + lrow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = wn0 + j * 16 + lq * 4;
+        if (n >= p.N) continue;
+        float* o = p.ws + ((long long)split * p.M + m) * p.N + n;
+        *reinterpret_cast<f32x4*>(o) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (VT && vt_tile[j]) {
+        // lane holds 4 consecutive pixels (rows) of channel n: transposed 8-byte store
+        const int n = wn0 + j * 16 + lrow;
+        const int m = wm0 + i * 16 + lq * 4;
+        if (n >= p.N || m >= p.M) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const float bb = p.bias ? p.bias[n] : 0.f;
+        const int b = m / p.OHW, pix = m - b * p.OHW;
+        bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
+        if (m + 3 < p.M && pix + 3 < p.OHW && ((p.vt_ld & 3) == 0) && ((pix & 3) == 0)) {
+          *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16)(v[0] + bb), (bf16)(v[1] + bb), (bf16)(v[2] + bb), (bf16)(v[3] + bb)};
+        } else {
+          for (int q = 0; q < 4; ++q) {
+            const int mq = m + q;
+            if (mq >= p.M) break;
+            const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
+            p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(v[q] + bb);
+          }
+        }
+        continue;
+      }
+      const int m = wm0 + i * 16 + lrow;
+      const int n = wn0 + j * 16 + lq * 4;
+      if (m >= p.M || n >= p.N) continue;
+      if (p.geglu) {
+        if (j & 1) continue;  // gate tile is consumed together with its value tile
+        float val[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const int jg = (j + 1 < NI) ? j + 1 : j;
+        float gate[4] = {acc[i][jg][0], acc[i][jg][1], acc[i][jg][2], acc[i][jg][3]};
+        if (p.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { val[q] += p.bias[n + q]; gate[q] += p.bias[n + 16 + q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] *= gelu_erf_f(gate[q]);
+        const int nout = ((n >> 5) << 4) + (n & 15);
+        finish_store4(p, m, nout, p.N >> 1, val);
+      } else {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        add_bias4(p, m, n, v);
+        finish_store4(p, m, n, p.N, v);
+      }
+    }
+  }
+}
+
+// ---- main kernel ------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int RP, bool VT>
+__global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int BROWS = BN + RP;
+  constexpr int A_PASSES = BM / 32, B_PASSES = BROWS / 32;
+  constexpr int RT_W = RP / 16 / WN;  // LoRA r-tiles (16 wide) computed by each wave
+  static_assert(RP == 0 || RT_W >= 1, "RP tiles must split over WN");
+  static_assert(NI % 2 == 0 || BN / WN == 16, "GEGLU pairs");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                        // [2][BM][128 B]
+  char* Bs = smem + 2 * BM * 128;         // [2][BROWS][128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int kt0 = split * p.kt_per_split;
+  const int kt1 = min(p.nkt, kt0 + p.kt_per_split);
+
+  // ---- per-thread gather state ----
+  const int kchunk = tid & 7, rbase = tid >> 3;
+  int a_b[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES];
+  bool a_ok[A_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < A_PASSES; ++ps) {
+    const int m = m0 + rbase + 32 * ps;
+    a_ok[ps] = m < p.M;
+    const int mm = a_ok[ps] ? m : 0;
+    const int b = mm / p.OHW;
+    const int pix = mm - b * p.OHW;
+    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    a_b[ps] = b;
+    a_ih0[ps] = oh * p.sh - p.ph;
+    a_iw0[ps] = ow * p.sw - p.pw;
+  }
+  int kc, kkh, kkw;  // channel / tap of this thread's chunk in the current K-tile
+  {
+    const int k = kt0 * BK + kchunk * 8;
+    const int tap = k / p.Ctot;
+    kc = k - tap * p.Ctot;
+    kkh = tap / p.KW;
+    kkw = tap - kkh * p.KW;
+  }
+  bf16x8 a_reg[A_PASSES], b_reg[B_PASSES];
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto gather = [&](int kt) {
+    // activations
+    const bool tap_ok = kkh < p.KH;
+    const bf16* src; int cs, Cs;
+    if (kc < p.Cin) { src = p.x; cs = kc; Cs = p.Cin; } else { src = p.x2; cs = kc - p.Cin; Cs = p.Cin2; }
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+      int ih = a_ih0[ps] + kkh * p.dh, iw = a_iw0[ps] + kkw * p.dw;
+      bool ok = a_ok[ps] && tap_ok;
+      if (p.UH > 0) {
+        ok = ok && (unsigned)ih < (unsigned)p.UH && (unsigned)iw < (unsigned)p.UW;
+        ih = (ih * p.IH) / p.UH;
+        iw = (iw * p.IW) / p.UW;
+      } else {
+        ok = ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      }
+      bf16x8 v = zero8;
+      if (ok) {
+        const long long off = ((long long)(a_b[ps] * p.IH + ih) * p.IW + iw) * Cs + cs;
+        v = *reinterpret_cast<const bf16x8*>(src + off);
+        if (p.in_act) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16)apply_act((float)v[j], p.in_act, p.in_slope);
+        }
+      }
+      a_reg[ps] = v;
+    }
+    // weights (+ LoRA-A rows appended)
+    const long long kofs = (long long)kt * BK + kchunk * 8;
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+      const int r = rbase + 32 * ps;
+      bf16x8 v = zero8;
+      if (r < BN) {
+        const int n = n0 + r;
+        if (n < p.N) v = *reinterpret_cast<const bf16x8*>(p.w + (long long)n * p.Kpad + kofs);
+      } else if (RP > 0) {
+        v = *reinterpret_cast<const bf16x8*>(p.lora_a + (long long)(r - BN) * p.Kpad + kofs);
+      }
+      b_reg[ps] = v;
+    }
+    // advance the tap/channel cursor by one K-tile
+    kc += BK;
+    while (kc >= p.Ctot) {
+      kc -= p.Ctot;
+      if (++kkw == p.KW) { kkw = 0; ++kkh; }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+      const int r = rbase + 32 * ps;
+      *reinterpret_cast<bf16x8*>(As + (buf * BM + r) * 128 + swz(r, kchunk) * 16) = a_reg[ps];
+    }
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+      const int r = rbase + 32 * ps;
+      *reinterpret_cast<bf16x8*>(Bs + (buf * BROWS + r) * 128 + swz(r, kchunk) * 16) = b_reg[ps];
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 tacc[MI][RT_W > 0 ? RT_W : 1];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < (RT_W > 0 ? RT_W : 1); ++j) tacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bool vt_tile[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) vt_tile[j] = VT && (n0 + wn * (BN / WN) + j * 16 >= p.vt_col0);
+
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  auto mma_step = [&](int buf, int ks, bool with_t) {
+    const int ch = ks * 4 + lq;
+    bf16x8 af[MI], wf[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int r = wm * (BM / WM) + i * 16 + lrow;
+      af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * 128 + swz(r, ch) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = wn * (BN / WN) + j * 16 + lrow;
+      wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BROWS + r) * 128 + swz(r, ch) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (VT && vt_tile[j])
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    if (RP > 0 && with_t) {
+#pragma unroll
+      for (int t = 0; t < RT_W; ++t) {
+        const int r = BN + (wn * RT_W + t) * 16 + lrow;
+        const bf16x8 lf = *reinterpret_cast<const bf16x8*>(Bs + (buf * BROWS + r) * 128 + swz(r, ch) * 16);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[i], tacc[i][t], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: one barrier per K-tile, register-staged double buffer ----
+  if (kt0 < kt1) {
+    gather(kt0);
+    stage(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) gather(kt + 1);
+    mma_step(buf, 0, true);
+    mma_step(buf, 1, true);
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- LoRA: T (bf16) -> LDS, then one more K-step against the pre-scaled B ----
+  if (RP > 0) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int t = 0; t < RT_W; ++t) {
+        const int r = wm * (BM / WM) + i * 16 + lrow;  // T row (pixel)
+        const int col = (wn * RT_W + t) * 16 + lq * 4; // T column (rank index)
+        bf16x4 tv = {(bf16)tacc[i][t][0], (bf16)tacc[i][t][1], (bf16)tacc[i][t][2], (bf16)tacc[i][t][3]};
+        *reinterpret_cast<bf16x4*>(As + r * 128 + swz(r, col >> 3) * 16 + (col & 7) * 2) = tv;
+        if (p.lora_t_out && tile_n == 0 && m0 + r < p.M)
+          *reinterpret_cast<bf16x4*>(p.lora_t_out + ((long long)split * p.M + m0 + r) * RP + col) = tv;
+      }
+    constexpr int RCH = RP > 0 ? RP / 8 : 1;
+    constexpr int LB_CHUNKS = BN * RCH;
+    for (int c = tid; c < LB_CHUNKS; c += THREADS) {
+      const int r = c / RCH, ch = c - r * RCH;
+      const int n = n0 + r;
+      bf16x8 v = zero8;
+      if (n < p.N) v = *reinterpret_cast<const bf16x8*>(p.lora_b + (long long)n * RP + ch * 8);
+      *reinterpret_cast<bf16x8*>(Bs + r * 128 + swz(r, ch) * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < RP / 32; ++ks) mma_step(0, ks, false);
+  }
+
+  igemm_epilogue<MI, NI, VT>(p, acc, vt_tile, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lrow, lq, split);
+}
+
+// ---- pipelined kernel: LDS-DMA (buffer_load ... lds) ring, counted vmcnt, one raw barrier per K-tile -------
+// The register-staged kernel above exposes a full HBM/L2 round trip per K-tile and spends hundreds of VALU
+// instructions per K-tile on gather addresses.  Here every 16-byte chunk of the activation gather and of the
+// weight tile goes global -> LDS directly (no VGPR staging) into an S-deep ring, S-1 K-tiles ahead of the
+// MFMAs; the only waits in the loop are a COUNTED s_waitcnt vmcnt((S-2)*L) and one s_barrier.
+//   * Requires Cin % 64 == 0 (and Cin2 % 64 == 0): a K-tile then lies inside ONE filter tap of ONE source, so
+//     the tap / source / channel cursor is SCALAR.  Per-lane byte offsets (pixel * C + chunk) are recomputed
+//     only when the tap or source changes; the channel advance inside a tap rides in the instruction's
+//     scalar offset, so steady-state K-tiles cost one buffer_load per 16-byte chunk and nothing else.
+//   * Zero padding uses the buffer descriptor's range check: padded taps get voffset 0x80000000 and the DMA
+//     writes zeros.  Rows past M / N are clamped (their results are never stored).
+//   * The LDS image is the same XOR-swizzled [row][64] layout: the DMA writes lane-linear, so the swizzle is
+//     applied to the per-lane SOURCE chunk instead (both-sides-or-neither).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+#endif
+
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
+__global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int BROWS = BN + RP;
+  constexpr int A_PASSES = BM / 32, W_PASSES = BN / 32, B_PASSES = BROWS / 32;
+  constexpr int L = A_PASSES + B_PASSES;   // LDS-DMA instructions per thread per K-tile
+  constexpr int D = S - 1;                 // K-tiles in flight ahead of the MFMAs
+  constexpr int STAGE = (BM + BROWS) * 128;
+  constexpr int RT_W = RP / 16 / WN;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert((D - 1) * L < 64, "vmcnt immediate");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [S][ A: BM x 128 B | B: BROWS x 128 B ]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int kt0 = split * p.kt_per_split;
+  const int kt1 = min(p.nkt, kt0 + p.kt_per_split);
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? (const void*)p.x2 : (const void*)p.x, p.x2 ? p.x2_bytes : p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+  const __amdgpu_buffer_rsrc_t rs_la = make_rsrc(RP > 0 ? (const void*)p.lora_a : (const void*)p.w, RP > 0 ? p.la_bytes : p.w_bytes);
+
+  // this lane DMA-writes physical chunk (tid & 7) of row (tid >> 3) + 32*pass; the logical (source) chunk is
+  // the swizzle's inverse image (the XOR is an involution and depends on (row >> 1) & 7 only, not on pass)
+  const int rbase = tid >> 3;
+  const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);
+  int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < A_PASSES; ++ps) {
+    const int m = min(m0 + rbase + 32 * ps, p.M - 1);
+    const int b = m / p.OHW;
+    const int pix = m - b * p.OHW;
+    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    a_pix0[ps] = b * p.IH * p.IW;
+    a_ih0[ps] = oh * p.sh - p.ph;
+    a_iw0[ps] = ow * p.sw - p.pw;
+  }
+  unsigned b_off[B_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < B_PASSES; ++ps) {
+    const int r = rbase + 32 * ps;
+    const int row = ps < W_PASSES ? min(n0 + r, p.N - 1) : r - BN;
+    b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
+  }
+  // scalar K cursor
+  int s_kh, s_kw, s_c0;
+  {
+    const int k = kt0 * BK;
+    const int tap = k / p.Ctot;
+    s_c0 = k - tap * p.Ctot;
+    s_kh = tap / p.KW;
+    s_kw = tap - s_kh * p.KW;
+  }
+  bool s_fresh = true;     // tap or source changed: per-lane offsets must be recomputed
+  unsigned cur_off[A_PASSES];
+  int a_soff = 0, b_soff = kt0 * BK * 2;
+  const int IHv = p.UH > 0 ? p.UH : p.IH, IWv = p.UW > 0 ? p.UW : p.IW;
+
+  auto issue = [&](int kt, int stage) {
+    char* sbase = smem + stage * STAGE + wave * 1024;   // + pass * 4096: this wave's 8 rows of the pass
+    const bool live = kt < kt1;
+    const bool src2 = s_c0 >= p.Cin;
+    if (live) {
+      if (s_fresh) {
+        const int Cs = src2 ? p.Cin2 : p.Cin;
+        const int dh = s_kh * p.dh, dw = s_kw * p.dw;
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+          int ih = a_ih0[ps] + dh, iw = a_iw0[ps] + dw;
+          const bool ok = (unsigned)ih < (unsigned)IHv && (unsigned)iw < (unsigned)IWv;
+          if (p.UH > 0) {
+            if (p.UH == 2 * p.IH) ih >>= 1; else ih = (ih * p.IH) / p.UH;
+            if (p.UW == 2 * p.IW) iw >>= 1; else iw = (iw * p.IW) / p.UW;
+          }
+          const unsigned off = (unsigned)(a_pix0[ps] + ih * p.IW + iw) * (unsigned)(Cs * 2) + kchunk * 16;
+          cur_off[ps] = ok ? off : OOB;
+        }
+        s_fresh = false;
+      }
+      a_soff = (s_c0 - (src2 ? p.Cin : 0)) * 2;
+      b_soff = kt * BK * 2;
+    }
+    if (src2) {
+#pragma unroll
+      for (int ps = 0; ps < A_PASSES; ++ps)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * 4096), 16, cur_off[ps], a_soff, 0, 0);
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < A_PASSES; ++ps)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + ps * 4096), 16, cur_off[ps], a_soff, 0, 0);
+    }
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+      if (ps < W_PASSES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * 128 + ps * 4096), 16, b_off[ps], b_soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_la, (lds_ptr_t)(sbase + BM * 128 + ps * 4096), 16, b_off[ps], b_soff, 0, 0);
+    }
+    if (live) {   // advance the scalar cursor by one K-tile
+      s_c0 += BK;
+      if (s_c0 == p.Cin && p.Cin2 > 0) s_fresh = true;
+      if (s_c0 >= p.Ctot) {
+        s_c0 = 0;
+        s_fresh = true;
+        if (++s_kw == p.KW) { s_kw = 0; ++s_kh; }
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 tacc[MI][RT_W > 0 ? RT_W : 1];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < (RT_W > 0 ? RT_W : 1); ++j) tacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the whole workgroup tile is either stored transposed (V^T columns) or not: vt_col0 % BN == 0 (host-checked),
+  // so the MFMA operand order is a per-workgroup constant and the main loop is instantiated once per order
+  const bool vt_wg = VT && (n0 >= p.vt_col0);
+  bool vt_tile[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) vt_tile[j] = vt_wg;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  auto mma_step = [&](auto vtf, const char* As, const char* Bs, int ks, bool with_t) {
+    const int ch = ks * 4 + lq;
+    bf16x8 af[MI], wf[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int r = wm * (BM / WM) + i * 16 + lrow;
+      af[i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + swz(r, ch) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = wn * (BN / WN) + j * 16 + lrow;
+      wf[j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + swz(r, ch) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if constexpr (decltype(vtf)::value)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    if (RP > 0 && with_t) {
+#pragma unroll
+      for (int t = 0; t < RT_W; ++t) {
+        const int r = BN + (wn * RT_W + t) * 16 + lrow;
+        const bf16x8 lf = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + swz(r, ch) * 16);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[i], tacc[i][t], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- ring: prologue fills D stages; steady state = wait(tile kt landed) -> barrier -> refill the stage
+  //      freed by tile kt-1 -> MFMAs on tile kt.  Tiles past the end are dummy zero-page loads so that the
+  //      vmcnt immediate stays constant.
+  char* const LBs = smem + S * STAGE;     // [BN][128 B] image of the pre-scaled LoRA-B tile (RP > 0 only)
+  if (RP > 0) {
+    // issued FIRST: vmcnt retires in order, so the first counted wait of the ring also covers these
+    const __amdgpu_buffer_rsrc_t rs_lb = make_rsrc(p.lora_b, p.lb_bytes);
+#pragma unroll
+    for (int ps = 0; ps < W_PASSES; ++ps) {
+      const int row = min(n0 + rbase + 32 * ps, p.N - 1);
+      const unsigned off = (kchunk < RP / 8) ? (unsigned)row * (unsigned)(RP * 2) + kchunk * 16 : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lb, (lds_ptr_t)(LBs + wave * 1024 + ps * 4096), 16, off, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(kt0 + s, s);
+  auto main_loop = [&](auto vtf) {
+    int st = 0, st_fill = D;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      wait_vmcnt<(D - 1) * L>();
+      __builtin_amdgcn_s_barrier();
+      issue(kt + D, st_fill);
+      mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 0, true);
+      mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 1, true);
+      st = (st + 1 == S) ? 0 : st + 1;
+      st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
+    }
+  };
+  if (VT && vt_wg) main_loop(std::true_type{}); else main_loop(std::false_type{});
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // ---- LoRA: T (bf16) -> LDS stage 0, then one more K-step against the pre-scaled B ----
+  if (RP > 0) {
+    char* As = smem;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int t = 0; t < RT_W; ++t) {
+        const int r = wm * (BM / WM) + i * 16 + lrow;
+        const int col = (wn * RT_W + t) * 16 + lq * 4;
+        bf16x4 tv = {(bf16)tacc[i][t][0], (bf16)tacc[i][t][1], (bf16)tacc[i][t][2], (bf16)tacc[i][t][3]};
+        *reinterpret_cast<bf16x4*>(As + r * 128 + swz(r, col >> 3) * 16 + (col & 7) * 2) = tv;
+        if (p.lora_t_out && tile_n == 0 && m0 + r < p.M)
+          *reinterpret_cast<bf16x4*>(p.lora_t_out + ((long long)split * p.M + m0 + r) * RP + col) = tv;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < RP / 32; ++ks) {
+      if (VT && vt_wg) mma_step(std::true_type{}, smem, LBs, ks, false);
+      else mma_step(std::false_type{}, smem, LBs, ks, false);
+    }
+  }
+  igemm_epilogue<MI, NI, VT>(p, acc, vt_tile, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lrow, lq, split);
+#endif
+}
+
+// ---- split-K reduce + epilogue ----------------------------------------------------------------
+static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev p) {
+  const int ncols = p.geglu ? (p.N >> 1) : p.N;
+  const int nq = ncols >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.M * nq) return;
+  const int m = (int)(idx / nq);
+  const int n = (int)(idx - (long long)m * nq) * 4;
+  if (p.geglu) {
+    const int nv = ((n >> 4) << 5) + (n & 15), ng = nv + 16;
+    float val[4] = {0, 0, 0, 0}, gate[4] = {0, 0, 0, 0};
+    for (int s = 0; s < p.splits; ++s) {
+      const float* wsr = p.ws + ((long long)s * p.M + m) * p.N;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(wsr + nv);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(wsr + ng);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { val[q] += a[q]; gate[q] += g[q]; }
+    }
+    if (p.bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { val[q] += p.bias[nv + q]; gate[q] += p.bias[ng + q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) val[q] *= gelu_erf_f(gate[q]);
+    finish_store4(p, m, n, ncols, val);
+  } else {
+    float v[4] = {0, 0, 0, 0};
+    for (int s = 0; s < p.splits; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws + ((long long)s * p.M + m) * p.N + n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += a[q];
+    }
+    add_bias4(p, m, n, v);
+    finish_store4(p, m, n, p.N, v);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
+int launch_cfg(const IgemmDev& d, hipStream_t st) {
+  // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
+  constexpr size_t lds = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
+  static bool attr_done = false;   // one-time, idempotent; races are benign
+  void (*kern)(const IgemmDev);
+  if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
+  else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { aldm_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  if (VT && d.vt_col0 % BN != 0) {
+    aldm_set_error("igemm: vt_col0 %d must be a multiple of the tile width %d", d.vt_col0, BN);
+    return ALDM_E_ARG;
+  }
+  IgemmDev dd = d;
+  dd.tiles_n = cdiv(d.N, BN);
+  dim3 grid(cdiv(d.M, BM) * dd.tiles_n, 1, d.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, st, dd);
+  return aldm_launch_status("igemm");
+}
+
+// S0 = ring depth without LoRA, SL = with LoRA (the LoRA rows + B tile cost LDS; SL is chosen so that the
+// workgroups-per-CU count does not drop, which matters more than ring depth for the short-K projection GEMMs)
+template <int BM, int BN, int WM, int WN, int S0, int SL>
+int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
+  if (vt) {
+    if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S0>(d, st);
+    if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, SL>(d, st);
+    return launch_cfg<BM, BN, WM, WN, 64, true, SL>(d, st);
+  }
+  if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S0>(d, st);
+  if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, SL>(d, st);
+  return launch_cfg<BM, BN, WM, WN, 64, false, SL>(d, st);
+}
+
+template <int BM, int BN, int WM, int WN, int S0, int SL>
+int launch_tile(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
+  // LDS-DMA ring needs a scalar K cursor (64-channel K-tiles inside one tap of one source), no gather-side
+  // activation and < 2 GiB activations (32-bit buffer offsets, 0x80000000 = "padded tap").
+  const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u &&
+                    d.x2_bytes < 0x80000000u;
+  if (!fast) return launch_rp<BM, BN, WM, WN, 0, 0>(d, Rp, vt, st);
+  return launch_rp<BM, BN, WM, WN, S0, SL>(d, Rp, vt, st);
+}
+
+
+}  // namespace aldm_igemm_detail

@@ -230,12 +230,13 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         ws = _workspace(splits * M * pw.N * 4, x.device)
         a.workspace = ws.data_ptr()
     if tile == 0:
-        tile = pick_tile(M, pw.N)
+        tile = _lib.TILE_64x64 if pw.Rp else pick_tile(M, pw.N)      # LoRA GEMMs are short-K: favour many workgroups
     a.tile = tile
     ktot = KH * KW * pw.Cin
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)
     nbytes = 2.0 * (B * IH * IW * pw.Cin + pw.N * ktot + M * ncols)
-    label = f"igemm_{TILE_NAMES[tile]}_r{pw.Rp}{'_vt' if vt is not None else ''}{'_sk' if splits > 1 else ''}"
+    label = (f"igemm_{TILE_NAMES[tile]}_r{pw.Rp}{'_vt' if vt is not None else ''}{'_sk' if splits > 1 else ''}"
+             f"|M{M} N{pw.N} K{ktot}{' geglu' if pw.geglu else ''}")
     lib = _lib.load()
     check(_launch(label, flops, nbytes, lambda: lib.aldm_igemm(C.byref(a), _stream())), "aldm_igemm")
     return out
@@ -256,7 +257,7 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load()
     n = B * H * W * (C1 + C2)
-    check(_launch("groupnorm", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(
+    check(_launch(f"groupnorm|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(
         _p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm")
     return y
 
@@ -266,7 +267,7 @@ def layernorm(x2d, gamma, beta, eps=1e-5):
     M, Cc = x2d.shape
     y = torch.empty_like(x2d)
     lib = _lib.load()
-    check(_launch("layernorm", 10.0 * M * Cc, 4.0 * M * Cc, lambda: lib.aldm_layernorm(
+    check(_launch(f"layernorm|M{M} C{Cc}", 10.0 * M * Cc, 4.0 * M * Cc, lambda: lib.aldm_layernorm(
         _p(x2d), M, Cc, _p(gamma), _p(beta), eps, _p(y), _stream())), "aldm_layernorm")
     return y
 

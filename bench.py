@@ -51,7 +51,7 @@ def synth_inputs(batch, height, width, seed_off=0):
     return lat, pe, ne
 
 
-def kernel_profile(engine):
+def kernel_profile(engine, fine=False):
     """One eager denoise step with an event pair around every launch; returns per-kernel-variant totals."""
     from audioldm_with_lora_amd import ops
     ops.PROFILE = []
@@ -60,6 +60,8 @@ def kernel_profile(engine):
     rows, ops.PROFILE = ops.PROFILE, None
     agg = {}
     for label, flops, nbytes, s, e in rows:
+        if not fine:
+            label = label.split("|")[0]
         a = agg.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         a["ms"] += s.elapsed_time(e)
         a["flops"] += flops
@@ -113,6 +115,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--fine", action="store_true", help="print the per-kernel-per-shape table to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,6 +168,9 @@ def main():
         prof = kernel_profile(eng)
         dom_label, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         total_ms = sum(v["ms"] for v in prof.values())
+        if args.fine:
+            for k, v in sorted(kernel_profile(eng, fine=True).items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"{k:64s} {v['launches']:3d}x {v['ms'] * 1e3 / v['launches']:7.1f} us  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:7.1f} TF/s", file=sys.stderr)
         if args.breakdown:
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"{k:32s} {v['launches']:4d} launches {v['ms']:8.3f} ms  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:8.1f} TF/s "

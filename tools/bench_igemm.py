@@ -70,6 +70,39 @@ def main():
                 tot[(t, sp)] = tot.get((t, sp), 0.0) + us
         print(line, flush=True)
     print("sum us:", {k: round(v, 1) for k, v in tot.items()})
+    if a.only and "qkv" not in a.only:
+        return
+    # transformer projections with the fused LoRA side channel (rank 4 on q,k,v / out) and the V^T store
+    for B, N, Cc in ((8, 1000, 256), (8, 252, 384), (8, 64, 640)):
+        M = B * N
+        x = torch.randn(M, Cc, device=dev).to(torch.bfloat16)
+        res = torch.randn(M, Cc, device=dev).to(torch.bfloat16)
+        wq = torch.randn(3 * Cc, Cc, device=dev) / math.sqrt(Cc)
+        A = [torch.randn(4, Cc, device=dev) / 4 for _ in range(3)]
+        Bm = [torch.randn(Cc, 4, device=dev) * 0.02 for _ in range(3)]
+        npad = (N + 7) // 8 * 8
+        vt = torch.empty(B, Cc, npad, device=dev, dtype=torch.bfloat16)
+        variants = {}
+        pw = ops.pack_linear(wq, None); variants["qkv plain"] = (pw, {})
+        pw = ops.pack_linear(wq, None); variants["qkv vt"] = (pw, dict(vt=vt, vt_col0=2 * Cc, vt_ld=npad, vt_batch_stride=Cc * npad))
+        pw = ops.pack_linear(wq, None); ops.attach_lora(pw, [(i * Cc, Cc, A[i], Bm[i], 1.0) for i in range(3)]); variants["qkv lora"] = (pw, {})
+        variants["qkv lora+vt"] = (pw, dict(vt=vt, vt_col0=2 * Cc, vt_ld=npad, vt_batch_stride=Cc * npad))
+        po = ops.pack_linear(wq[:Cc], torch.zeros(Cc, device=dev)); variants["out plain+res"] = (po, dict(res=res.view(B, 1, N, Cc)))
+        po2 = ops.pack_linear(wq[:Cc], torch.zeros(Cc, device=dev)); ops.attach_lora(po2, [(0, Cc, A[0], Bm[0], 1.0)]); variants["out lora+res"] = (po2, dict(res=res.view(B, 1, N, Cc)))
+        for t in tiles:
+            line = f"C={Cc} N={N} tile{t}: "
+            for name, (pw, kw) in variants.items():
+                xx = x.view(B, 1, N, Cc)
+                ops.conv(xx, pw, tile=t, **kw)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    ops.conv(xx, pw, tile=t, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                line += f"{name}: {e0.elapsed_time(e1) * 1e3 / a.reps:6.1f}us | "
+            print(line, flush=True)
 
 
 if __name__ == "__main__":
