@@ -19,6 +19,7 @@ class IgemmArgs(C.Structure):
         ("x", C.c_void_p), ("x2", C.c_void_p),
         ("B", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int), ("Cin2", C.c_int),
         ("UH", C.c_int), ("UW", C.c_int),
+        ("in_dilate", C.c_int),
         ("w", C.c_void_p),
         ("Kpad", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("stride_h", C.c_int), ("stride_w", C.c_int),
@@ -56,6 +57,26 @@ PROTOTYPES = {
                                  C.c_void_p]),
     "aldm_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_attention_lse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p]),
+    "aldm_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aldm_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                     C.c_void_p]),
+    "aldm_geglu_fwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "aldm_upsample_nearest_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p]),
+    "aldm_tn_small": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_lora_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_transpose_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_mse_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aldm_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                     C.c_void_p]),
     "aldm_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
                                                             const bf16* __restrict__ k, int ldk,
                                                             const bf16* __restrict__ vt, int vt_ld, long long vt_bs,
                                                             int N, int D, float c /* scale*log2(e) */,
-                                                            bf16* __restrict__ out, int out_ld) {
+                                                            bf16* __restrict__ out, int out_ld, float* __restrict__ lse) {
   using Cfg = AttnCfg<DP>;
   constexpr int T = 64 * NW;
   constexpr int DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS;
@@ -194,6 +194,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
+  if (lse && hh == 0 && q0 + r < N)   // log2-domain log-sum-exp of the scaled scores: p = exp2(s*c - lse)
+    lse[((long long)b * gridDim.y + head) * N + q0 + r] = m_run + __log2f(l_tot);
   if (q0 + r < N) {
     bf16* orow = out + ((long long)b * N + q0 + r) * out_ld + head * D;
 #pragma unroll
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 
 template <int DP, int NW>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
-                int H, int D, float scale, void* out, int out_ld, hipStream_t st) {
+                int H, int D, float scale, void* out, int out_ld, float* lse, hipStream_t st) {
   using Cfg = AttnCfg<DP>;
   auto kern = attention_kernel<DP, NW>;
   static bool attr_done = false;
@@ -222,16 +224,16 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, 
   attr_done = true;
   dim3 grid(cdiv(N, 32 * NW), H, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), Cfg::LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt,
-                     vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld);
+                     vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld, lse);
   return aldm_launch_status("attention");
 }
 
 template <int DP>
 int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
-                  int H, int D, float scale, void* out, int out_ld, hipStream_t st) {
-  if (N >= 512) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
-  if (N >= 128) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
-  return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
+                  int H, int D, float scale, void* out, int out_ld, float* lse, hipStream_t st) {
+  if (N >= 512) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, st);
+  if (N >= 128) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, st);
+  return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, st);
 }
 
 // ---- row softmax (VAE mid-block attention runs QK^T / PV through the GEMM kernel) ----
@@ -258,15 +260,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
-                              long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
-                              void* stream) {
+static int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                          long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                          float* lse, void* stream) {
   ALDM_CHECK_ARG(q && k && vt && out, "attention: null pointer");
   ALDM_CHECK_ARG(B > 0 && N > 0 && H > 0 && d > 0, "attention: bad dims");
   ALDM_CHECK_ARG(d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0, "attention: d/ld must be multiples of 8");
   ALDM_CHECK_ARG(vt_ld >= ((N + 7) / 8) * 8, "attention: vt_ld %d too small for N %d", vt_ld, N);
   hipStream_t st = (hipStream_t)stream;
-#define ALDM_ATTN(DPV) return launch_attn_d<DPV>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, st)
+#define ALDM_ATTN(DPV) return launch_attn_d<DPV>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, st)
   if (d <= 16) ALDM_ATTN(16);
   if (d <= 32) ALDM_ATTN(32);
   if (d <= 48) ALDM_ATTN(48);
@@ -275,6 +277,19 @@ extern "C" int aldm_attention(const void* q, int ldq, const void* k, int ldk, co
 #undef ALDM_ATTN
   aldm_set_error("attention: head dim %d > 80 is handled by the GEMM path", d);
   return ALDM_E_UNSUPPORTED;
+}
+
+extern "C" int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                              long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                              void* stream) {
+  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, stream);
+}
+
+extern "C" int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                                  long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                                  float* lse, void* stream) {
+  ALDM_CHECK_ARG(lse, "attention_lse: null lse");
+  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, stream);
 }
 
 extern "C" int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out,

@@ -1,0 +1,338 @@
+// Flash-style attention BACKWARD for gfx950 (LoRA fine-tune step: dX through the frozen SDPA of
+// UNet2DConditionModel [REF script/train/train_audioldm_lora.py:539-557]).  P is recomputed from Q, K and the
+// forward's log2-domain LSE; the N x N matrices never touch HBM.  Two kernels, both built like the forward:
+//   attn_bwd_dq  : a wave owns 32 QUERY columns.  S^T = K Q^T and dP^T = V dO^T (keys on rows), so
+//                  lse / delta are lane-local; dS^T is converted in registers and re-used as the B operand of
+//                  dQ^T += K^T dS^T (K^T token-major from LDS) -- same accumulator-as-operand trick as the forward.
+//                  Also emits delta = rowsum(dO * O).
+//   attn_bwd_dkv : a wave owns 32 KEY columns.  S = Q K^T and dP = dO V^T (queries on rows); P and dS feed
+//                  dV^T += dO^T P and dK^T += Q^T dS with Q^T / dO^T token-major from LDS.  No atomics anywhere:
+//                  every output element has exactly one owner.
+// Token-major copies (Q^T, K^T, dO^T as [B][C][Npad]) come from aldm_transpose_tokens.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 64;   // tokens per staged tile
+constexpr int VS = 136;  // token-major LDS row stride (64 tokens * 2 B + 8 B pad)
+
+template <int DP>
+struct BwdCfg {
+  static constexpr int DK = DP / 16;
+  static constexpr int DT = (DP + 31) / 32;
+  static constexpr int KS = DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);   // row-major LDS row stride
+  static constexpr int RBYTES = TS * KS;          // one row-major tile
+  static constexpr int TBYTES = DT * 32 * VS;     // one token-major tile
+};
+
+// cooperative tile loaders ---------------------------------------------------------------------
+template <int DP, int T>
+__device__ __forceinline__ void load_rows(char* dst, const bf16* base, int ld, int t0, int N, int D, int tid) {
+  constexpr int KS = BwdCfg<DP>::KS;
+  constexpr int CH = TS * (DP / 8);
+  for (int c = tid; c < CH; c += T) {
+    const int row = c / (DP / 8), ch = c - row * (DP / 8);
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t0 + row < N && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(base + (long long)(t0 + row) * ld + ch * 8);
+    *reinterpret_cast<bf16x8*>(dst + row * KS + ch * 16) = v;
+  }
+}
+template <int DP, int T>
+__device__ __forceinline__ void load_tokmajor(char* dst, const bf16* base, int ldt, int t0, int N, int D, int tid) {
+  constexpr int DT = BwdCfg<DP>::DT;
+  constexpr int CH = DT * 32 * (TS / 8);
+  for (int c = tid; c < CH; c += T) {
+    const int row = c >> 3, ch = c & 7;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int tb = t0 + ch * 8;
+    if (row < D && tb < N) {
+      v = *reinterpret_cast<const bf16x8*>(base + (long long)row * ldt + tb);
+      if (tb + 8 > N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (tb + j >= N) v[j] = (bf16)0.f;
+      }
+    }
+    uint2* d2 = reinterpret_cast<uint2*>(dst + row * VS + ch * 16);
+    const uint4 u = __builtin_bit_cast(uint4, v);
+    d2[0] = make_uint2(u.x, u.y);
+    d2[1] = make_uint2(u.z, u.w);
+  }
+}
+
+__device__ __forceinline__ bf16x8 read_tok_frag(const char* tile, int row, int s2, int hh) {
+  const char* p = tile + row * VS + (16 * s2 + 4 * hh) * 2;
+  const uint2 lo = *reinterpret_cast<const uint2*>(p);
+  const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+// ---- dQ ------------------------------------------------------------------------------------------
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                              const bf16* __restrict__ v, int ld,
+                                                              const bf16* __restrict__ kT, int ldt, long long t_bs,
+                                                              const bf16* __restrict__ dO, const bf16* __restrict__ O, int ldo,
+                                                              const float* __restrict__ lse, float* __restrict__ delta,
+                                                              int N, int D, float scale, bf16* __restrict__ dq, int lddq) {
+  using Cfg = BwdCfg<DP>;
+  constexpr int T = 64 * NW, DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                       // K rows   [64][KS]
+  char* Vs = Ks + Cfg::RBYTES;           // V rows   [64][KS]
+  char* KTs = Vs + Cfg::RBYTES;          // K^T      [DT*32][VS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
+  const float c = scale * 1.44269504088896340736f;
+  const long long rowbase = (long long)b * N;
+  const bf16* qb = q + rowbase * ld + head * D;
+  const bf16* kb = k + rowbase * ld + head * D;
+  const bf16* vb = v + rowbase * ld + head * D;
+  const bf16* dob = dO + rowbase * ldo + head * D;
+  const bf16* ob = O + rowbase * ldo + head * D;
+  const bf16* ktb = kT + (long long)b * t_bs + (long long)head * D * ldt;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  bf16x8 qf[DK], dof[DK];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) {
+    const int col = 16 * ks + 8 * hh;
+    const bool ok = q0 + r < N && col < D;
+    qf[ks] = ok ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + r) * ld + col) : zero8;
+    dof[ks] = ok ? *reinterpret_cast<const bf16x8*>(dob + (long long)(q0 + r) * ldo + col) : zero8;
+    const bf16x8 of = ok ? *reinterpret_cast<const bf16x8*>(ob + (long long)(q0 + r) * ldo + col) : zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+  }
+  dl += __shfl_xor(dl, 32, 64);            // delta_q = sum_d dO[q][d] * O[q][d]
+  float L = 0.f;
+  if (q0 + r < N) {
+    L = lse[((long long)b * H + head) * N + q0 + r];
+    if (hh == 0) delta[((long long)b * H + head) * N + q0 + r] = dl;
+  }
+
+  f32x16 acc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const int ntiles = (N + TS - 1) / TS;
+  for (int it = 0; it < ntiles; ++it) {
+    const int kv0 = it * TS;
+    __syncthreads();
+    load_rows<DP, T>(Ks, kb, ld, kv0, N, D, tid);
+    load_rows<DP, T>(Vs, vb, ld, kv0, N, D, tid);
+    load_tokmajor<DP, T>(KTs, ktb, ldt, kv0, N, D, tid);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+      }
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kvr = kv0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const float p = kvr < N ? __builtin_amdgcn_exp2f(fmaf(s[i], c, -L)) : 0.f;
+        dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - dl));
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tok_frag(KTs, t * 32 + r, sub * 2 + s2, hh), dsf[s2], acc[t], 0, 0, 0);
+    }
+  }
+  if (q0 + r < N) {
+    bf16* orow = dq + (rowbase + q0 + r) * lddq + head * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * hh;
+        if (d0 < D) {
+          bf16x4 o = {(bf16)(acc[t][4 * g] * scale), (bf16)(acc[t][4 * g + 1] * scale), (bf16)(acc[t][4 * g + 2] * scale), (bf16)(acc[t][4 * g + 3] * scale)};
+          *reinterpret_cast<bf16x4*>(orow + d0) = o;
+        }
+      }
+  }
+}
+
+// ---- dK, dV --------------------------------------------------------------------------------------
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                               const bf16* __restrict__ v, int ld,
+                                                               const bf16* __restrict__ qT, const bf16* __restrict__ dOT,
+                                                               int ldt, long long qt_bs, long long dot_bs,
+                                                               const bf16* __restrict__ dO, int ldo,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               int N, int D, float scale, bf16* __restrict__ dk,
+                                                               bf16* __restrict__ dv, int lddk) {
+  using Cfg = BwdCfg<DP>;
+  constexpr int T = 64 * NW, DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;                          // Q rows    [64][KS]
+  char* dOs = Qs + Cfg::RBYTES;             // dO rows   [64][KS]
+  char* QTs = dOs + Cfg::RBYTES;            // Q^T       [DT*32][VS]
+  char* dOTs = QTs + Cfg::TBYTES;           // dO^T      [DT*32][VS]
+  float* Ls = reinterpret_cast<float*>(dOTs + Cfg::TBYTES);   // [64] lse, [64] delta
+  float* Ds = Ls + TS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int kv0 = (blockIdx.x * NW + wave) * 32;
+  const float c = scale * 1.44269504088896340736f;
+  const long long rowbase = (long long)b * N;
+  const bf16* qb = q + rowbase * ld + head * D;
+  const bf16* kb = k + rowbase * ld + head * D;
+  const bf16* vb = v + rowbase * ld + head * D;
+  const bf16* dob = dO + rowbase * ldo + head * D;
+  const bf16* qtb = qT + (long long)b * qt_bs + (long long)head * D * ldt;
+  const bf16* dotb = dOT + (long long)b * dot_bs + (long long)head * D * ldt;
+  const float* lb = lse + ((long long)b * H + head) * N;
+  const float* db = delta + ((long long)b * H + head) * N;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  bf16x8 kf[DK], vf[DK];   // B operands: lane (key column r, half hh) holds K/V[kv0 + r][16 ks + 8 hh ..]
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) {
+    const int col = 16 * ks + 8 * hh;
+    const bool ok = kv0 + r < N && col < D;
+    kf[ks] = ok ? *reinterpret_cast<const bf16x8*>(kb + (long long)(kv0 + r) * ld + col) : zero8;
+    vf[ks] = ok ? *reinterpret_cast<const bf16x8*>(vb + (long long)(kv0 + r) * ld + col) : zero8;
+  }
+  f32x16 accv[DT], acck[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accv[t][i] = 0.f; acck[t][i] = 0.f; }
+
+  const int ntiles = (N + TS - 1) / TS;
+  for (int it = 0; it < ntiles; ++it) {
+    const int qt0 = it * TS;
+    __syncthreads();
+    load_rows<DP, T>(Qs, qb, ld, qt0, N, D, tid);
+    load_rows<DP, T>(dOs, dob, ldo, qt0, N, D, tid);
+    load_tokmajor<DP, T>(QTs, qtb, ldt, qt0, N, D, tid);
+    load_tokmajor<DP, T>(dOTs, dotb, ldt, qt0, N, D, tid);
+    for (int i = tid; i < TS; i += T) {
+      Ls[i] = qt0 + i < N ? lb[qt0 + i] : 0.f;
+      Ds[i] = qt0 + i < N ? db[qt0 + i] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(Qs + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
+        const bf16x8 dofr = *reinterpret_cast<const bf16x8*>(dOs + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], s, 0, 0, 0);      // S[q rows][key cols]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], dp, 0, 0, 0);   // dP[q rows][key cols]
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ql = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;     // query row inside the staged tile
+        const float p = (qt0 + ql < N) ? __builtin_amdgcn_exp2f(fmaf(s[i], c, -Ls[ql])) : 0.f;
+        pf[i >> 3][i & 7] = (bf16)p;
+        dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - Ds[ql]));
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          accv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tok_frag(dOTs, t * 32 + r, sub * 2 + s2, hh), pf[s2], accv[t], 0, 0, 0);
+          acck[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tok_frag(QTs, t * 32 + r, sub * 2 + s2, hh), dsf[s2], acck[t], 0, 0, 0);
+        }
+    }
+  }
+  if (kv0 + r < N) {
+    bf16* krow = dk + (rowbase + kv0 + r) * lddk + head * D;
+    bf16* vrow = dv + (rowbase + kv0 + r) * lddk + head * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * hh;
+        if (d0 < D) {
+          bf16x4 ok_ = {(bf16)(acck[t][4 * g] * scale), (bf16)(acck[t][4 * g + 1] * scale), (bf16)(acck[t][4 * g + 2] * scale), (bf16)(acck[t][4 * g + 3] * scale)};
+          bf16x4 ov_ = {(bf16)accv[t][4 * g], (bf16)accv[t][4 * g + 1], (bf16)accv[t][4 * g + 2], (bf16)accv[t][4 * g + 3]};
+          *reinterpret_cast<bf16x4*>(krow + d0) = ok_;
+          *reinterpret_cast<bf16x4*>(vrow + d0) = ov_;
+        }
+      }
+  }
+}
+
+template <int DP, int NW>
+int launch_bwd(const void* q, const void* k, const void* v, int ld, const void* qT, const void* kT, const void* dOT, int ldt,
+               long long qt_bs, long long kt_bs, long long dot_bs, const void* dO, const void* O, int ldo, const float* lse,
+               float* delta, int B, int N, int H, int D, float scale, void* dq, void* dk, void* dv, int ldg, hipStream_t st) {
+  using Cfg = BwdCfg<DP>;
+  constexpr int lds_a = 2 * Cfg::RBYTES + Cfg::TBYTES;
+  constexpr int lds_b = 2 * Cfg::RBYTES + 2 * Cfg::TBYTES + 2 * TS * 4;
+  auto ka = attn_bwd_dq_kernel<DP, NW>;
+  auto kb = attn_bwd_dkv_kernel<DP, NW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    attr_done = true;
+  }
+  dim3 grid(cdiv(N, 32 * NW), H, B);
+  hipLaunchKernelGGL(ka, grid, dim3(64 * NW), lds_a, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, ld, (const bf16*)kT,
+                     ldt, kt_bs, (const bf16*)dO, (const bf16*)O, ldo, lse, delta, N, D, scale, (bf16*)dq, ldg);
+  int rc = aldm_launch_status("attn_bwd_dq");
+  if (rc) return rc;
+  hipLaunchKernelGGL(kb, grid, dim3(64 * NW), lds_b, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, ld, (const bf16*)qT,
+                     (const bf16*)dOT, ldt, qt_bs, dot_bs, (const bf16*)dO, ldo, lse, (const float*)delta, N, D, scale,
+                     (bf16*)dk, (bf16*)dv, ldg);
+  return aldm_launch_status("attn_bwd_dkv");
+}
+
+template <int DP>
+int launch_bwd_d(const void* q, const void* k, const void* v, int ld, const void* qT, const void* kT, const void* dOT, int ldt,
+                 long long qt_bs, long long kt_bs, long long dot_bs, const void* dO, const void* O, int ldo, const float* lse,
+                 float* delta, int B, int N, int H, int D, float scale, void* dq, void* dk, void* dv, int ldg, hipStream_t st) {
+  if (N >= 512) return launch_bwd<DP, 4>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
+  if (N >= 128) return launch_bwd<DP, 2>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
+  return launch_bwd<DP, 1>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
+}
+
+}  // namespace
+
+extern "C" int aldm_attention_bwd(const void* q, const void* k, const void* v, int ld, const void* qT, const void* kT,
+                                  const void* dOT, int ldt, long long qT_batch_stride, long long kT_batch_stride,
+                                  long long dOT_batch_stride, const void* dO, const void* O, int ldo, const float* lse,
+                                  float* delta, int B, int N, int H, int d, float scale, void* dq, void* dk, void* dv,
+                                  int ldg, void* stream) {
+  ALDM_CHECK_ARG(q && k && v && qT && kT && dOT && dO && O && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
+  ALDM_CHECK_ARG(B > 0 && N > 0 && H > 0 && d > 0 && d % 8 == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldt % 8 == 0 && ldg % 4 == 0,
+                 "attention_bwd: bad dims");
+  ALDM_CHECK_ARG(ldt >= ((N + 7) / 8) * 8, "attention_bwd: ldt %d too small for N %d", ldt, N);
+  hipStream_t st = (hipStream_t)stream;
+#define ALDM_BWD(DPV) return launch_bwd_d<DPV>(q, k, v, ld, qT, kT, dOT, ldt, qT_batch_stride, kT_batch_stride, dOT_batch_stride, dO, O, ldo, lse, delta, B, N, H, d, scale, dq, dk, dv, ldg, st)
+  if (d <= 16) ALDM_BWD(16);
+  if (d <= 32) ALDM_BWD(32);
+  if (d <= 48) ALDM_BWD(48);
+  if (d <= 64) ALDM_BWD(64);
+  if (d <= 80) ALDM_BWD(80);
+#undef ALDM_BWD
+  aldm_set_error("attention_bwd: head dim %d > 80 unsupported", d);
+  return ALDM_E_UNSUPPORTED;
+}

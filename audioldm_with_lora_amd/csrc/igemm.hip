@@ -41,13 +41,14 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
+  ALDM_CHECK_ARG(p->in_dilate == 0 || (p->in_dilate == 2 && p->UH == 0), "igemm: in_dilate must be 0 or 2 (and excludes UH/UW)");
 
   IgemmDev d;
   d.x = (const bf16*)p->x; d.x2 = (const bf16*)p->x2; d.w = (const bf16*)p->w;
   d.lora_a = (const bf16*)p->lora_a; d.lora_b = (const bf16*)p->lora_b; d.lora_t_out = (bf16*)p->lora_t_out;
   d.bias = p->bias; d.rowbias = p->rowbias; d.res = (const bf16*)p->res; d.res2 = (const bf16*)p->res2;
   d.out = p->out; d.vt = (bf16*)p->vt; d.ws = p->workspace;
-  d.B = p->B; d.IH = p->IH; d.IW = p->IW; d.Cin = p->Cin; d.Cin2 = p->Cin2; d.Ctot = Ctot; d.UH = p->UH; d.UW = p->UW;
+  d.B = p->B; d.IH = p->IH; d.IW = p->IW; d.Cin = p->Cin; d.Cin2 = p->Cin2; d.Ctot = Ctot; d.UH = p->UH; d.UW = p->UW; d.dilate = p->in_dilate;
   d.KH = p->KH; d.KW = p->KW; d.sh = p->stride_h; d.sw = p->stride_w; d.ph = p->pad_h; d.pw = p->pad_w;
   d.dh = p->dil_h; d.dw = p->dil_w;
   d.OH = p->OH; d.OW = p->OW; d.OHW = p->OH * p->OW; d.N = p->Cout; d.M = p->B * p->OH * p->OW; d.Kpad = p->Kpad;

@@ -31,7 +31,7 @@ struct IgemmDev {
   bf16* lora_t_out;
   const float* bias; const float* rowbias; const bf16* res; const bf16* res2;
   void* out; bf16* vt; float* ws;
-  int B, IH, IW, Cin, Cin2, Ctot, UH, UW;
+  int B, IH, IW, Cin, Cin2, Ctot, UH, UW, dilate;
   int KH, KW, sh, sw, ph, pw, dh, dw;
   int OH, OW, OHW, N, M, Kpad;
   int in_act; float in_slope;
@@ -245,7 +245,11 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
     for (int ps = 0; ps < A_PASSES; ++ps) {
       int ih = a_ih0[ps] + kkh * p.dh, iw = a_iw0[ps] + kkw * p.dw;
       bool ok = a_ok[ps] && tap_ok;
-      if (p.UH > 0) {
+      if (p.dilate == 2) {
+        ok = ok && ih >= 0 && iw >= 0 && !((ih | iw) & 1) && (ih >> 1) < p.IH && (iw >> 1) < p.IW;
+        ih >>= 1;
+        iw >>= 1;
+      } else if (p.UH > 0) {
         ok = ok && (unsigned)ih < (unsigned)p.UH && (unsigned)iw < (unsigned)p.UW;
         ih = (ih * p.IH) / p.UH;
         iw = (iw * p.IW) / p.UW;
@@ -495,8 +499,12 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
           int ih = a_ih0[ps] + dh, iw = a_iw0[ps] + dw;
-          const bool ok = (unsigned)ih < (unsigned)IHv && (unsigned)iw < (unsigned)IWv;
-          if (p.UH > 0) {
+          bool ok = (unsigned)ih < (unsigned)IHv && (unsigned)iw < (unsigned)IWv;
+          if (p.dilate == 2) {
+            ok = ih >= 0 && iw >= 0 && !((ih | iw) & 1) && (ih >> 1) < p.IH && (iw >> 1) < p.IW;
+            ih >>= 1;
+            iw >>= 1;
+          } else if (p.UH > 0) {
             if (p.UH == 2 * p.IH) ih >>= 1; else ih = (ih * p.IH) / p.UH;
             if (p.UW == 2 * p.IW) iw >>= 1; else iw = (iw * p.IW) / p.UW;
           }

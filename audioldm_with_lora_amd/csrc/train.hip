@@ -1,0 +1,449 @@
+// Backward / training kernels of the LoRA fine-tune step on gfx950 (configs 3/4):
+// the loop body [REF script/train/train_audioldm_lora.py:499-565]  add_noise -> UNet -> MSE -> backward -> AdamW,
+// with the base model frozen [REF train:374-376]: only dX flows through the frozen ops and only the LoRA
+// A/B matrices receive weight gradients [REF train:378-385].
+//
+//   groupnorm_bwd / layernorm_bwd   dX of F.group_norm(+SiLU) / F.layer_norm (statistics recomputed in registers)
+//   geglu_fwd / geglu_bwd           GEGLU kept un-fused in training so the projection is available to the backward
+//   upsample_nearest_bwd            adjoint of the nearest up-sampling folded into the up-sampler convs
+//   tn_small                        dA = U^T X and dB = dY^T T: rank-r "reduce over tokens" products, scattered straight
+//                                   into the flat fp32 LoRA gradient buffer that RCCL all-reduces
+//   lora_pack                       flat fp32 LoRA parameters -> the bf16 packed operands of the fused GEMMs (one launch)
+//   transpose_tokens                [B*N][C] row-major -> [B][C][Npad] token-major (attention operands)
+//   mse_grad                        eps-prediction MSE loss value and its gradient
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 512;
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red, int tid) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = a; red[8 + (tid >> 6)] = b; }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN_THREADS / 64; ++i) { ta += red[i]; tb += red[8 + i]; }
+  a = ta; b = tb;
+}
+
+// y = act(gn(x)) ; given dy -> dx.  One workgroup per (image, group), strip in registers (<= 512*QPT quads).
+template <int QPT>
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x2,
+                                                                   const bf16* __restrict__ dy, int HW, int C1, int C2,
+                                                                   int groups, float eps, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, int act,
+                                                                   bf16* __restrict__ dx, bf16* __restrict__ dx2) {
+  __shared__ float red[16];
+  const int C = C1 + C2;
+  const int Cg = C / groups, qpp = Cg >> 2;
+  const int nb = gridDim.x / groups;
+  const int g = blockIdx.x / nb, b = blockIdx.x - g * nb;
+  const int c0 = g * Cg;
+  const int nquads = HW * qpp;
+  const int tid = threadIdx.x;
+
+  bf16x4 v[QPT], d[QPT];
+  float s = 0.f, dummy = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + i * GN_THREADS;
+    bf16x4 t = {0, 0, 0, 0}, u = {0, 0, 0, 0};
+    if (q < nquads) {
+      const int pix = q / qpp, j = q - pix * qpp;
+      const int c = c0 + 4 * j;
+      t = (c < C1) ? *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c)
+                   : *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
+      u = *reinterpret_cast<const bf16x4*>(dy + ((long long)b * HW + pix) * C + c);
+    }
+    v[i] = t;
+    d[i] = u;
+    s += (float)t[0] + (float)t[1] + (float)t[2] + (float)t[3];
+  }
+  const float n = (float)nquads * 4.f;
+  block_sum2(s, dummy, red, tid);
+  const float mean = s / n;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i)
+    if (tid + i * GN_THREADS < nquads) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float e = (float)v[i][k] - mean; ss += e * e; }
+    }
+  dummy = 0.f;
+  block_sum2(ss, dummy, red, tid);
+  const float rstd = rsqrtf(ss / n + eps);
+
+  // gdz = dz * gamma kept in fp32 registers would double the footprint: recompute it in the second sweep
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + i * GN_THREADS;
+    if (q < nquads) {
+      const int j = q - (q / qpp) * qpp;
+      const int c = c0 + 4 * j;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = ((float)v[i][k] - mean) * rstd;
+        float dz = (float)d[i][k];
+        if (act == ALDM_ACT_SILU) {
+          const float z = xh * gamma[c + k] + beta[c + k];
+          const float sg = 1.f / (1.f + __expf(-z));
+          dz *= sg * (1.f + z * (1.f - sg));
+        }
+        const float gd = dz * gamma[c + k];
+        s1 += gd;
+        s2 += gd * xh;
+      }
+    }
+  }
+  block_sum2(s1, s2, red, tid);
+  s1 /= n;
+  s2 /= n;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + i * GN_THREADS;
+    if (q < nquads) {
+      const int pix = q / qpp, j = q - pix * qpp;
+      const int c = c0 + 4 * j;
+      bf16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = ((float)v[i][k] - mean) * rstd;
+        float dz = (float)d[i][k];
+        if (act == ALDM_ACT_SILU) {
+          const float z = xh * gamma[c + k] + beta[c + k];
+          const float sg = 1.f / (1.f + __expf(-z));
+          dz *= sg * (1.f + z * (1.f - sg));
+        }
+        o[k] = (bf16)(rstd * (dz * gamma[c + k] - s1 - xh * s2));
+      }
+      if (c < C1) *reinterpret_cast<bf16x4*>(dx + ((long long)b * HW + pix) * C1 + c) = o;
+      else if (dx2) *reinterpret_cast<bf16x4*>(dx2 + ((long long)b * HW + pix) * C2 + (c - C1)) = o;
+    }
+  }
+}
+
+constexpr int LN_MAXC = 4;
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int M,
+                                                            int C, const float* __restrict__ gamma, float eps,
+                                                            bf16* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C >> 3;
+  const bf16* xr = x + (long long)row * C;
+  const bf16* dr = dy + (long long)row * C;
+  bf16x8 v[LN_MAXC], d[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      v[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+      d[i] = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += (float)v[i][k];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float e = (float)v[i][k] - mean; ss += e * e; }
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = ((float)v[i][k] - mean) * rstd;
+        const float gd = (float)d[i][k] * gamma[ch * 8 + k];
+        s1 += gd;
+        s2 += gd * xh;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+  bf16* o = dx + (long long)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      bf16x8 r;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = ((float)v[i][k] - mean) * rstd;
+        r[k] = (bf16)(rstd * ((float)d[i][k] * gamma[ch * 8 + k] - s1 - xh * s2));
+      }
+      *reinterpret_cast<bf16x8*>(o + ch * 8) = r;
+    }
+  }
+}
+
+// h [M][2I] in blocks of (16 value | 16 gate) (the packing of ops.pack_geglu) -> out [M][I] = value * gelu_erf(gate)
+__global__ void geglu_fwd_kernel(const bf16* __restrict__ h, long long M, int I, bf16* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over M * I / 4
+  const int q = I >> 2;
+  if (idx >= M * q) return;
+  const long long m = idx / q;
+  const int n = (int)(idx - m * q) * 4;
+  const int nv = ((n >> 4) << 5) + (n & 15);
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(h + m * 2 * I + nv);
+  const bf16x4 g = *reinterpret_cast<const bf16x4*>(h + m * 2 * I + nv + 16);
+  bf16x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)a[k] * gelu_erf_f((float)g[k]));
+  *reinterpret_cast<bf16x4*>(out + m * I + n) = o;
+}
+
+__global__ void geglu_bwd_kernel(const bf16* __restrict__ h, const bf16* __restrict__ dout, long long M, int I,
+                                 bf16* __restrict__ dh) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = I >> 2;
+  if (idx >= M * q) return;
+  const long long m = idx / q;
+  const int n = (int)(idx - m * q) * 4;
+  const int nv = ((n >> 4) << 5) + (n & 15);
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(h + m * 2 * I + nv);
+  const bf16x4 g = *reinterpret_cast<const bf16x4*>(h + m * 2 * I + nv + 16);
+  const bf16x4 d = *reinterpret_cast<const bf16x4*>(dout + m * I + n);
+  bf16x4 da, dg;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gv = (float)g[k], dv = (float)d[k];
+    const float cdf = 0.5f * (1.f + erff(gv * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * gv * gv);
+    da[k] = (bf16)(dv * gv * cdf);
+    dg[k] = (bf16)(dv * (float)a[k] * (cdf + gv * pdf));
+  }
+  *reinterpret_cast<bf16x4*>(dh + m * 2 * I + nv) = da;
+  *reinterpret_cast<bf16x4*>(dh + m * 2 * I + nv + 16) = dg;
+}
+
+__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, long long n, bf16* __restrict__ c) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + i), y = *reinterpret_cast<const bf16x8*>(b + i);
+    bf16x8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (bf16)((float)x[k] + (float)y[k]);
+    *reinterpret_cast<bf16x8*>(c + i) = z;
+  } else {
+    for (long long j = i; j < n; ++j) c[j] = (bf16)((float)a[j] + (float)b[j]);
+  }
+}
+
+// dx[b][ih][iw][c] = sum of dy over the nearest-neighbour preimage of (ih, iw)
+__global__ void upsample_nearest_bwd_kernel(const bf16* __restrict__ dy, int B, int IH, int IW, int OH, int OW, int C,
+                                            bf16* __restrict__ dx) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*IH*IW*C/8
+  const int cq = C >> 3;
+  if (idx >= (long long)B * IH * IW * cq) return;
+  const int c = (int)(idx % cq) * 8;
+  long long t = idx / cq;
+  const int iw = (int)(t % IW); t /= IW;
+  const int ih = (int)(t % IH);
+  const int b = (int)(t / IH);
+  const int oh0 = (ih * OH + IH - 1) / IH, oh1 = ((ih + 1) * OH + IH - 1) / IH;
+  const int ow0 = (iw * OW + IW - 1) / IW, ow1 = ((iw + 1) * OW + IW - 1) / IW;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int oh = oh0; oh < oh1; ++oh)
+    for (int ow = ow0; ow < ow1; ++ow) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (((long long)b * OH + oh) * OW + ow) * C + c);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (bf16)acc[k];
+  *reinterpret_cast<bf16x8*>(dx + (((long long)b * IH + ih) * IW + iw) * C + c) = o;
+}
+
+// out[p][q] += sum_m P[m][p] * Q[m][q]  (P: [M][Rp] bf16, Q: [M][ldq] bf16 columns q0..q0+Qc), rank rows p < Rp <= 64.
+// Row p of the product is scattered by `rows[p]`: dst[(q - qlo) * qstride] += scale * value for q in [qlo, qhi).
+struct TnRow { float* dst; int qlo, qhi, qstride; float scale; };
+template <int RP>
+__global__ __launch_bounds__(256) void tn_small_kernel(const bf16* __restrict__ P, const bf16* __restrict__ Q, int M, int ldq,
+                                                       int Qc, const TnRow* __restrict__ rows, int m_per_block) {
+  constexpr int PR = RP / 4;                 // rank rows per thread
+  __shared__ float Ps[32][RP];
+  __shared__ float Qs[32][64];
+  const int tid = threadIdx.x, tq = tid & 63, tp = tid >> 6;
+  const int q0 = blockIdx.x * 64;
+  const int mb = blockIdx.y * m_per_block, me = min(M, mb + m_per_block);
+  float acc[PR];
+#pragma unroll
+  for (int i = 0; i < PR; ++i) acc[i] = 0.f;
+  for (int m0 = mb; m0 < me; m0 += 32) {
+    __syncthreads();
+    for (int i = tid; i < 32 * RP; i += 256) {
+      const int mm = i / RP, pp = i - mm * RP;
+      Ps[mm][pp] = (m0 + mm < me) ? (float)P[(long long)(m0 + mm) * RP + pp] : 0.f;
+    }
+    for (int i = tid; i < 32 * 64; i += 256) {
+      const int mm = i >> 6, qq = i & 63;
+      Qs[mm][qq] = (m0 + mm < me && q0 + qq < Qc) ? (float)Q[(long long)(m0 + mm) * ldq + q0 + qq] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int mm = 0; mm < 32; ++mm) {
+      const float qv = Qs[mm][tq];
+#pragma unroll
+      for (int i = 0; i < PR; ++i) acc[i] += Ps[mm][tp * PR + i] * qv;
+    }
+  }
+  const int q = q0 + tq;
+  if (q < Qc) {
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const TnRow r = rows[tp * PR + i];
+      if (r.dst && q >= r.qlo && q < r.qhi) atomicAdd(r.dst + (long long)(q - r.qlo) * r.qstride, acc[i] * r.scale);
+    }
+  }
+}
+
+struct PackJob { const float* src; bf16* dst; int rows, cols, src_ld, dst_ld, transpose; float scale; };
+__global__ void lora_pack_kernel(const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.x];
+  const int n = j.rows * j.cols;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / j.cols, c = i - r * j.cols;
+    const float v = j.src[(long long)r * j.src_ld + c] * j.scale;
+    if (j.transpose) j.dst[(long long)c * j.dst_ld + r] = (bf16)v;
+    else j.dst[(long long)r * j.dst_ld + c] = (bf16)v;
+  }
+}
+
+// in: rows [B*N][ld_in], columns c0..c0+C  ->  out [B][C][Npad] (token-contiguous), 64x64 LDS tiles
+__global__ __launch_bounds__(256) void transpose_tokens_kernel(const bf16* __restrict__ in, int ld_in, int N, int C, int Npad,
+                                                               bf16* __restrict__ out) {
+  __shared__ bf16 tile[64][66];
+  const int b = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (n0 + r < N && c0 + c < C) ? in[((long long)b * N + n0 + r) * ld_in + c0 + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < C && n0 + r < Npad) out[((long long)b * C + c0 + c) * Npad + n0 + r] = tile[r][c];
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       long long n, float gscale, bf16* __restrict__ dpred,
+                                                       float* __restrict__ loss) {
+  __shared__ float red[4];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float e = 0.f;
+  if (i < n) {
+    e = pred[i] - target[i];
+    dpred[i] = (bf16)(2.f * e / (float)n * gscale);
+  }
+  float s = wave_sum(e * e);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) / (float)n);
+}
+
+inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
+                                  float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2,
+                                  void* stream) {
+  ALDM_CHECK_ARG(x && dy && dx && gamma && beta && B > 0 && HW > 0, "groupnorm_bwd: bad args");
+  const int C = C1 + C2;
+  ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0 && (C2 == 0 || x2), "groupnorm_bwd: bad channels");
+  const long long nquads = (long long)HW * (C / groups / 4);
+  ALDM_CHECK_ARG(nquads <= 32 * GN_THREADS, "groupnorm_bwd: strip of %lld quads exceeds the register-resident limit", nquads);
+#define ALDM_GNB(QPT)                                                                                                  \
+  hipLaunchKernelGGL(groupnorm_bwd_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
+                     (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
+                     (bf16*)dx, (bf16*)dx2)
+  if (nquads <= 4 * GN_THREADS) ALDM_GNB(4);
+  else if (nquads <= 8 * GN_THREADS) ALDM_GNB(8);
+  else if (nquads <= 16 * GN_THREADS) ALDM_GNB(16);
+  else ALDM_GNB(32);
+#undef ALDM_GNB
+  return aldm_launch_status("groupnorm_bwd");
+}
+
+extern "C" int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx,
+                                  void* stream) {
+  ALDM_CHECK_ARG(x && dy && dx && gamma && M > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "layernorm_bwd: bad args");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                     (const bf16*)dy, M, C, gamma, eps, (bf16*)dx);
+  return aldm_launch_status("layernorm_bwd");
+}
+
+extern "C" int aldm_geglu_fwd(const void* h, long long M, int I, void* out, void* stream) {
+  ALDM_CHECK_ARG(h && out && M > 0 && I % 16 == 0, "geglu_fwd: bad args");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(nblk(M * (I / 4), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, M, I, (bf16*)out);
+  return aldm_launch_status("geglu_fwd");
+}
+
+extern "C" int aldm_geglu_bwd(const void* h, const void* dout, long long M, int I, void* dh, void* stream) {
+  ALDM_CHECK_ARG(h && dout && dh && M > 0 && I % 16 == 0, "geglu_bwd: bad args");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblk(M * (I / 4), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, (const bf16*)dout, M, I, (bf16*)dh);
+  return aldm_launch_status("geglu_bwd");
+}
+
+extern "C" int aldm_add_bf16(const void* a, const void* b, long long n, void* c, void* stream) {
+  ALDM_CHECK_ARG(a && b && c && n > 0, "add_bf16: bad args");
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, n, (bf16*)c);
+  return aldm_launch_status("add_bf16");
+}
+
+extern "C" int aldm_upsample_nearest_bwd(const void* dy, int B, int IH, int IW, int OH, int OW, int C, void* dx, void* stream) {
+  ALDM_CHECK_ARG(dy && dx && B > 0 && IH > 0 && IW > 0 && OH >= IH && OW >= IW && C % 8 == 0, "upsample_nearest_bwd: bad args");
+  hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(nblk((long long)B * IH * IW * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)dy, B, IH, IW, OH, OW, C, (bf16*)dx);
+  return aldm_launch_status("upsample_nearest_bwd");
+}
+
+extern "C" int aldm_tn_small(const void* P, int Rp, const void* Q, int ldq, int Qc, int M, const void* rows_dev, void* stream) {
+  ALDM_CHECK_ARG(P && Q && rows_dev && M > 0 && Qc > 0 && (Rp == 32 || Rp == 64), "tn_small: bad args");
+  const int qt = cdiv(Qc, 64);
+  int msplit = 512 / qt;
+  if (msplit < 1) msplit = 1;
+  int mpb = cdiv(cdiv(M, msplit), 32) * 32;
+  if (mpb < 64) mpb = 64;
+  dim3 grid(qt, cdiv(M, mpb));
+  if (Rp == 32)
+    hipLaunchKernelGGL(tn_small_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)P, (const bf16*)Q, M, ldq, Qc, (const TnRow*)rows_dev, mpb);
+  else
+    hipLaunchKernelGGL(tn_small_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)P, (const bf16*)Q, M, ldq, Qc, (const TnRow*)rows_dev, mpb);
+  return aldm_launch_status("tn_small");
+}
+
+extern "C" int aldm_lora_pack(const void* jobs_dev, int njobs, void* stream) {
+  ALDM_CHECK_ARG(jobs_dev && njobs > 0, "lora_pack: bad args");
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev);
+  return aldm_launch_status("lora_pack");
+}
+
+extern "C" int aldm_transpose_tokens(const void* in, int ld_in, int B, int N, int C, int Npad, void* out, void* stream) {
+  ALDM_CHECK_ARG(in && out && B > 0 && N > 0 && C > 0 && Npad >= N, "transpose_tokens: bad args");
+  hipLaunchKernelGGL(transpose_tokens_kernel, dim3(cdiv(Npad, 64), cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)in, ld_in, N, C, Npad, (bf16*)out);
+  return aldm_launch_status("transpose_tokens");
+}
+
+extern "C" int aldm_mse_grad(const float* pred, const float* target, long long n, float grad_scale, void* dpred, float* loss,
+                             void* stream) {
+  ALDM_CHECK_ARG(pred && target && dpred && loss && n > 0, "mse_grad: bad args");
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, target, n, grad_scale, (bf16*)dpred, loss);
+  return aldm_launch_status("mse_grad");
+}

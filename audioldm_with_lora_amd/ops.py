@@ -161,7 +161,7 @@ def _workspace(nbytes, device):
 
 
 def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, stride=(1, 1), pad=(0, 0), dil=(1, 1),
-         up_size=None, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
+         up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
          splits=None, tile=0):
@@ -195,6 +195,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     a.x, a.x2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
     a.B, a.IH, a.IW, a.Cin, a.Cin2 = B, IH, IW, C1, C2
     a.UH, a.UW = (up_size if up_size is not None else (0, 0))
+    a.in_dilate = in_dilate
     a.w, a.Kpad = pw.w.data_ptr(), pw.Kpad
     a.KH, a.KW = KH, KW
     a.stride_h, a.stride_w = stride
@@ -352,3 +353,113 @@ def advance_step(step_idx, timesteps_f32, t_out):
 def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     check(_lib.load().aldm_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
                                       grad_scale, _stream()), "aldm_adamw_flat")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training-side wrappers (LoRA fine-tune step)
+# ---------------------------------------------------------------------------------------------------------
+def transpose_tokens(x2d, B, N, Cc, npad=None):
+    """rows [B*N, C] -> token-major [B, C, Npad] (zero padded)."""
+    _require_gpu(x2d)
+    npad = npad or (N + 7) // 8 * 8
+    out = torch.empty(B, Cc, npad, dtype=torch.bfloat16, device=x2d.device)
+    check(_lib.load().aldm_transpose_tokens(_p(x2d), x2d.stride(0), B, N, Cc, npad, _p(out), _stream()), "aldm_transpose_tokens")
+    return out
+
+
+def attention_train(qkv, qkvT, B, N, H, d):
+    """qkv [B*N, 3C] row-major, qkvT [B, 3C, Npad] token-major -> (out [B*N, C], lse [B, H, N] fp32)."""
+    Cc = H * d
+    out = torch.empty(B * N, Cc, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    base, tb = qkv.data_ptr(), qkvT.data_ptr()
+    npad = qkvT.shape[2]
+    check(_lib.load().aldm_attention_lse(C.c_void_p(base), 3 * Cc, C.c_void_p(base + 2 * Cc), 3 * Cc,
+                                         C.c_void_p(tb + 2 * (2 * Cc) * npad), npad, 3 * Cc * npad, B, N, H, d,
+                                         1.0 / math.sqrt(d), _p(out), Cc, _p(lse), _stream()), "aldm_attention_lse")
+    return out, lse
+
+
+def attention_bwd(qkv, qkvT, dO, O, lse, B, N, H, d):
+    """-> dqkv [B*N, 3C] (dQ | dK | dV)."""
+    Cc = H * d
+    npad = qkvT.shape[2]
+    dOT = transpose_tokens(dO, B, N, Cc, npad)
+    dqkv = torch.empty(B * N, 3 * Cc, dtype=torch.bfloat16, device=qkv.device)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    base, tb, gb = qkv.data_ptr(), qkvT.data_ptr(), dqkv.data_ptr()
+    check(_lib.load().aldm_attention_bwd(
+        C.c_void_p(base), C.c_void_p(base + 2 * Cc), C.c_void_p(base + 4 * Cc), 3 * Cc,
+        C.c_void_p(tb), C.c_void_p(tb + 2 * Cc * npad), _p(dOT), npad, 3 * Cc * npad, 3 * Cc * npad, Cc * npad,
+        _p(dO), _p(O), Cc, _p(lse), _p(delta), B, N, H, d, 1.0 / math.sqrt(d),
+        C.c_void_p(gb), C.c_void_p(gb + 2 * Cc), C.c_void_p(gb + 4 * Cc), 3 * Cc, _stream()), "aldm_attention_bwd")
+    return dqkv
+
+
+def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True):
+    B, H, W, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x2) if (x2 is not None and need_dx2) else None
+    check(_lib.load().aldm_groupnorm_bwd(_p(x), _p(x2), _p(dy), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act,
+                                         _p(dx), _p(dx2), _stream()), "aldm_groupnorm_bwd")
+    return dx, dx2
+
+
+def layernorm_bwd(x2d, dy, gamma, eps=1e-5):
+    M, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    check(_lib.load().aldm_layernorm_bwd(_p(x2d), _p(dy), M, Cc, _p(gamma), eps, _p(dx), _stream()), "aldm_layernorm_bwd")
+    return dx
+
+
+def geglu_fwd(h):
+    M, two_i = h.shape
+    out = torch.empty(M, two_i // 2, dtype=torch.bfloat16, device=h.device)
+    check(_lib.load().aldm_geglu_fwd(_p(h), M, two_i // 2, _p(out), _stream()), "aldm_geglu_fwd")
+    return out
+
+
+def geglu_bwd(h, dout):
+    dh = torch.empty_like(h)
+    check(_lib.load().aldm_geglu_bwd(_p(h), _p(dout), h.shape[0], h.shape[1] // 2, _p(dh), _stream()), "aldm_geglu_bwd")
+    return dh
+
+
+def add_bf16(a, b):
+    c = torch.empty_like(a)
+    check(_lib.load().aldm_add_bf16(_p(a), _p(b), a.numel(), _p(c), _stream()), "aldm_add_bf16")
+    return c
+
+
+def upsample_nearest_bwd(dy, ih, iw):
+    B, OH, OW, Cc = dy.shape
+    dx = torch.empty(B, ih, iw, Cc, dtype=torch.bfloat16, device=dy.device)
+    check(_lib.load().aldm_upsample_nearest_bwd(_p(dy), B, ih, iw, OH, OW, Cc, _p(dx), _stream()), "aldm_upsample_nearest_bwd")
+    return dx
+
+
+def tn_small(P, Q, rows_dev, Qc=None):
+    """flat_grad rows += P^T Q  through the device row table (see aldm_tn_small)."""
+    M, Rp = P.shape
+    check(_lib.load().aldm_tn_small(_p(P), Rp, _p(Q), Q.stride(0), Qc or Q.shape[1], M, _p(rows_dev), _stream()), "aldm_tn_small")
+
+
+def lora_pack(jobs_dev, njobs):
+    check(_lib.load().aldm_lora_pack(_p(jobs_dev), njobs, _stream()), "aldm_lora_pack")
+
+
+def mse_grad(pred, target, loss, grad_scale=1.0):
+    dp = torch.empty(pred.shape, dtype=torch.bfloat16, device=pred.device)
+    check(_lib.load().aldm_mse_grad(_p(pred), _p(target), pred.numel(), grad_scale, _p(dp), _p(loss), _stream()), "aldm_mse_grad")
+    return dp
+
+
+def pack_conv_bwd(weight, lo=0, hi=None):
+    """dX weights of a stride-1 'same' conv: Wt[cin][(kh, kw, cout)] = W[cout][cin][KH-1-kh][KW-1-kw] for cin in [lo, hi)."""
+    w = weight.detach()[:, lo:hi]
+    return pack_conv(w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), None)
+
+
+def pack_linear_bwd(weight, lo=0, hi=None):
+    return pack_linear(weight.detach().t()[lo:hi].contiguous(), None)

@@ -53,6 +53,7 @@ typedef struct {
   const void* x;  const void* x2;
   int B, IH, IW, Cin, Cin2;
   int UH, UW;               /* >0: conv runs on the nearest-upsampled image of this size */
+  int in_dilate;            /* 2: conv runs on the zero-dilated image x[2i] (adjoint of a stride-2 conv); else 0 */
   /* filter */
   const void* w;            /* [Cout][Kpad] bf16, K index = (kh*KW+kw)*(Cin+Cin2) + c */
   int Kpad;
@@ -114,6 +115,19 @@ int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* v
                    long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                    void* stream);
 
+/* Same, additionally writing the log2-domain log-sum-exp of the scaled scores, lse [B][H][N] fp32 (training). */
+int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                       long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                       float* lse, void* stream);
+/* Flash-style backward of the same op: dQ, dK, dV [B*N][ldg] (head h at columns h*d) from q,k,v row-major [B*N][ld],
+   token-major copies qT,kT,dOT [B][C][ldt] (aldm_transpose_tokens), dO, O [B*N][ldo] and the forward's lse.
+   delta [B][H][N] fp32 is scratch (rowsum(dO*O)).  No atomics: bitwise reproducible. */
+int aldm_attention_bwd(const void* q, const void* k, const void* v, int ld, const void* qT, const void* kT,
+                       const void* dOT, int ldt, long long qT_batch_stride, long long kT_batch_stride,
+                       long long dOT_batch_stride, const void* dO, const void* O, int ldo, const float* lse,
+                       float* delta, int B, int N, int H, int d, float scale, void* dq, void* dk, void* dv,
+                       int ldg, void* stream);
+
 /* Row softmax of fp32 scores [rows][cols] (ld) -> bf16 probabilities (VAE mid-block attention, N=4000, d=512). */
 int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out, void* stream);
 
@@ -146,6 +160,31 @@ int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float*
    [REF script/train/train_audioldm_lora.py:504]); fp32 in, fp32 out; coef fp32 [B][2] = {sqrt(abar_t), sqrt(1-abar_t)} */
 int aldm_add_noise(const float* x, const float* noise, const float* coef, int B, long long n_per_sample, float* out,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward kernels of the LoRA fine-tune step [REF script/train/train_audioldm_lora.py:499-565]: the base model
+ * is frozen, so only dX flows through GroupNorm / LayerNorm / GEGLU / up-sampling, and only the LoRA matrices get
+ * weight gradients (aldm_tn_small).  dX of convolutions / linears is aldm_igemm with transposed weights.
+ * ------------------------------------------------------------------------------------------ */
+int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
+                       float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2, void* stream);
+int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx, void* stream);
+/* GEGLU on the interleaved (16 value | 16 gate) projection h [M][2I]: out [M][I] = value * gelu(gate), and its backward */
+int aldm_geglu_fwd(const void* h, long long M, int I, void* out, void* stream);
+int aldm_geglu_bwd(const void* h, const void* dout, long long M, int I, void* dh, void* stream);
+int aldm_add_bf16(const void* a, const void* b, long long n, void* c, void* stream);
+int aldm_upsample_nearest_bwd(const void* dy, int B, int IH, int IW, int OH, int OW, int C, void* dx, void* stream);
+/* out[p][q] += sum_m P[m][p] * Q[m][q]  (P [M][Rp], Q [M][ldq] bf16; Rp = 32 or 64).  Row p is scattered through the
+   device table rows_dev[p] = {float* dst; int qlo, qhi, qstride; float scale}: dst[(q-qlo)*qstride] += scale*value for
+   qlo <= q < qhi (fp32 atomics into the flat LoRA gradient buffer). */
+int aldm_tn_small(const void* P, int Rp, const void* Q, int ldq, int Qc, int M, const void* rows_dev, void* stream);
+/* jobs_dev[i] = {const float* src; bf16* dst; int rows, cols, src_ld, dst_ld, transpose; float scale}: one launch converts
+   the flat fp32 LoRA parameters into every packed bf16 operand of the fused GEMMs. */
+int aldm_lora_pack(const void* jobs_dev, int njobs, void* stream);
+/* rows [B*N][ld_in] (C columns) -> [B][C][Npad] token-major, zero padded */
+int aldm_transpose_tokens(const void* in, int ld_in, int B, int N, int C, int Npad, void* out, void* stream);
+/* loss[0] += mean((pred-target)^2) ; dpred = 2 (pred-target)/n * grad_scale (bf16)  (F.mse_loss, [REF train:549]) */
+int aldm_mse_grad(const float* pred, const float* target, long long n, float grad_scale, void* dpred, float* loss, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training helpers (configs 3/4): fused AdamW over one flat fp32 LoRA buffer
