@@ -1,0 +1,420 @@
+"""LoRA fine-tune step on the MI355X HIP path (configs 3 / 4).
+
+Replaces the loop body of the reference trainer  [REF script/train/train_audioldm_lora.py:499-565]:
+    noisy = scheduler.add_noise(latents, noise, t) ; pred = unet(noisy, t, class_labels=emb)
+    loss = mse(pred, noise) ; backward ; AdamW on the LoRA parameters ; polynomial LR
+with the base model frozen [REF train:374-376] and LoRA injected by peft-style config [REF train:378-385].
+
+There is no torch autograd here.  A small launch tape records, per forward op, the HIP launches of its backward:
+  * dX through convolutions / linears = the SAME implicit-GEMM kernel with transposed (and tap-flipped) weights;
+    stride-2 convs use the zero-dilated gather, up-sampler convs the nearest adjoint
+  * LoRA sites run forward AND backward as ONE fused GEMM each:   y  = x W^T + (x A^T)(sB)^T        saves T = x A^T
+                                                                  dx = dy W  + (dy sB) A            saves U = dy sB
+    then  dB = s dy^T T  and  dA = U^T x  are rank-r "reduce over tokens" products scattered with fp32 atomics
+    straight into ONE flat gradient buffer -- the buffer RCCL all-reduces and the flat AdamW kernel consumes
+  * GroupNorm / LayerNorm / GEGLU / attention backward are dedicated kernels (train.hip, attention_bwd.hip)
+All LoRA parameters live in one flat fp32 buffer (the nn.Parameters are views into it); one `aldm_lora_pack`
+launch per step refreshes every packed bf16 operand.
+"""
+import math
+import struct
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import dp, ops
+from ._lib import ACT_NONE, ACT_SILU
+from .lora import LoraLinear
+from .unet import UNet2DConditionModel
+
+BK = 64
+
+
+# ----------------------------------------------------------------------------------------------
+# tape
+# ----------------------------------------------------------------------------------------------
+class Var:
+    __slots__ = ("t", "g", "rg")
+
+    def __init__(self, t, rg=False):
+        self.t, self.g, self.rg = t, None, rg
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def acc(v, g):
+    if v is None or not v.rg:
+        return
+    v.g = g if v.g is None else ops.add_bf16(v.g, g.reshape(v.g.shape))
+
+
+class Tape:
+    def __init__(self):
+        self.fns = []
+
+    def record(self, fn):
+        self.fns.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns.clear()
+
+
+def _bwd_pack(pw, lo, hi):
+    """dX weights from the packed forward weights: Wt[c][(kh', kw', n)] = W[n][KH-1-kh'][KW-1-kw'][c], c in [lo, hi)."""
+    key = (lo, hi)
+    cache = pw.__dict__.setdefault("_bwd", {})
+    if key not in cache:
+        n, kh, kw, c = pw.N, pw.KH, pw.KW, pw.Cin
+        w = pw.w[:, :kh * kw * c].view(n, kh, kw, c)[:, :, :, lo:hi]
+        wt = w.flip(1, 2).permute(3, 1, 2, 0).reshape(hi - lo, kh * kw * n)
+        cache[key] = ops.PackedW(ops._pad_k(wt), None, hi - lo, n, kh, kw)
+    return cache[key]
+
+
+def t_view(tape, x, shape):
+    y = Var(x.t.view(shape), x.rg)
+    if x.rg:
+        tape.record(lambda: acc(x, y.g.view(x.t.shape)) if y.g is not None else None)
+    return y
+
+
+def t_conv(tape, x, pw, x2=None, stride=(1, 1), pad=(0, 0), up_size=None, rowbias=None, rowbias_ld=0, res=None, out_f32=False):
+    """Frozen conv / linear (no LoRA): forward = ops.conv, backward = dX only."""
+    y = Var(ops.conv(x.t, pw, x2=(x2.t if x2 is not None else None), stride=stride, pad=pad, up_size=up_size,
+                     rowbias=rowbias, rowbias_ld=rowbias_ld, res=(res.t if res is not None else None), out_f32=out_f32, splits=1 if out_f32 else None))
+    y.rg = x.rg or (x2 is not None and x2.rg) or (res is not None and res.rg)
+    if not y.rg:
+        return y
+    c1 = x.t.shape[3]
+
+    def bwd():
+        dy = y.g
+        if dy is None:
+            return
+        acc(res, dy)
+        bpad = (pw.KH - 1 - pad[0], pw.KW - 1 - pad[1])
+        for src, lo, hi in ((x, 0, c1), (x2, c1, pw.Cin)):
+            if src is None or not src.rg:
+                continue
+            bw = _bwd_pack(pw, lo, hi)
+            ih, iw = src.t.shape[1], src.t.shape[2]
+            if stride == (2, 2):
+                dx = ops.conv(dy, bw, pad=bpad, in_dilate=2, out_hw=(ih, iw))
+            elif up_size is not None:
+                dx = ops.upsample_nearest_bwd(ops.conv(dy, bw, pad=bpad), ih, iw)
+            else:
+                dx = ops.conv(dy, bw, pad=bpad)
+            acc(src, dx)
+    tape.record(bwd)
+    return y
+
+
+def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None):
+    y = Var(ops.groupnorm(x.t, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None)))
+    y.rg = x.rg or (x2 is not None and x2.rg)
+    if y.rg:
+        def bwd():
+            if y.g is None:
+                return
+            dx, dx2 = ops.groupnorm_bwd(x.t, y.g, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None),
+                                        need_dx2=(x2 is not None and x2.rg))
+            acc(x, dx)
+            acc(x2, dx2)
+        tape.record(bwd)
+    return y
+
+
+def t_layernorm(tape, x, gamma, beta):
+    y = Var(ops.layernorm(x.t, gamma, beta), x.rg)
+    if x.rg:
+        tape.record(lambda: acc(x, ops.layernorm_bwd(x.t, y.g, gamma)) if y.g is not None else None)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# LoRA sites: one per fused projection GEMM (q|k|v together, out-proj alone)
+# ----------------------------------------------------------------------------------------------
+class LoraSite:
+    """Packed operands + gradient scatter tables of one LoRA-bearing GEMM."""
+
+    def __init__(self, weight, bias, parts, flat, dev):
+        # parts: list of (row0, nrows, A param, B param, scaling)
+        self.N, self.K = weight.shape
+        self.parts = parts
+        rtot = sum(p[2].shape[0] for p in parts)
+        self.Rp = 32 if rtot <= 32 else 64
+        assert rtot <= 64, "combined LoRA rank per GEMM must be <= 64"
+        npad = (self.N + BK - 1) // BK * BK
+        self.fwd = ops.pack_linear(weight, bias)
+        self.fwd.lora_a = torch.zeros(self.Rp, self.fwd.Kpad, dtype=torch.bfloat16, device=dev)
+        self.fwd.lora_b = torch.zeros(self.N, self.Rp, dtype=torch.bfloat16, device=dev)
+        self.fwd.Rp = self.Rp
+        self.bwd = ops.PackedW(ops._pad_k(weight.detach().t().contiguous()), None, self.K, self.N)
+        self.bwd.lora_a = torch.zeros(self.Rp, npad, dtype=torch.bfloat16, device=dev)
+        self.bwd.lora_b = torch.zeros(self.K, self.Rp, dtype=torch.bfloat16, device=dev)
+        self.bwd.Rp = self.Rp
+        self.jobs = []
+        rows_db = [(0, 0, 0, 0, 0.0)] * self.Rp
+        rows_da = [(0, 0, 0, 0, 0.0)] * self.Rp
+        col = 0
+        for row0, nrows, A, Bm, s in parts:
+            r, k = A.shape
+            oa, ob = flat.offset_of(A), flat.offset_of(Bm)
+            pa, pb = flat.params.data_ptr() + 4 * oa, flat.params.data_ptr() + 4 * ob
+            ga, gb = flat.grads.data_ptr() + 4 * oa, flat.grads.data_ptr() + 4 * ob
+            self.jobs += [
+                (pa, self.fwd.lora_a.data_ptr() + 2 * col * self.fwd.Kpad, r, k, k, self.fwd.Kpad, 0, 1.0),
+                (pb, self.fwd.lora_b.data_ptr() + 2 * (row0 * self.Rp + col), nrows, r, r, self.Rp, 0, s),
+                (pb, self.bwd.lora_a.data_ptr() + 2 * (col * npad + row0), nrows, r, r, npad, 1, s),
+                (pa, self.bwd.lora_b.data_ptr() + 2 * col, r, k, k, self.Rp, 1, 1.0),
+            ]
+            for j in range(r):
+                rows_db[col + j] = (gb + 4 * j, row0, row0 + nrows, r, s)        # dB[n][j] = s * sum_m dy[m][n] T[m][col+j]
+                rows_da[col + j] = (ga + 4 * j * k, 0, k, 1, 1.0)                # dA[j][k] = sum_m U[m][col+j] x[m][k]
+            col += r
+        pack = lambda rows: torch.frombuffer(bytearray(b"".join(struct.pack("<qiiif", *r) for r in rows)), dtype=torch.uint8).to(dev)
+        self.rows_db, self.rows_da = pack(rows_db), pack(rows_da)
+
+
+def t_lora_linear(tape, x, site, res=None):
+    """x [M, K] -> y [M, N] with the LoRA side channel; records dX + dA/dB."""
+    M = x.t.shape[0]
+    T = torch.empty(M, site.Rp, dtype=torch.bfloat16, device=x.t.device)
+    y = Var(ops.linear(x.t, site.fwd, res=(res.t if res is not None else None), lora_t_out=T, splits=1), True)
+
+    def bwd():
+        dy = y.g
+        if dy is None:
+            return
+        acc(res, dy)
+        U = torch.empty(M, site.Rp, dtype=torch.bfloat16, device=dy.device)
+        dx = ops.linear(dy, site.bwd, lora_t_out=U, splits=1)     # dx = dy W + (dy sB) A ; U = dy sB
+        acc(x, dx)
+        ops.tn_small(T, dy, site.rows_db, Qc=site.N)
+        ops.tn_small(U, x.t, site.rows_da, Qc=site.K)
+    tape.record(bwd)
+    return y
+
+
+def _lin_parts(mod, row0):
+    if isinstance(mod, LoraLinear):
+        return (row0, mod.base_layer.out_features, mod.lora_A["default"].weight, mod.lora_B["default"].weight, mod.scaling)
+    return None
+
+
+def _base(mod):
+    return mod.base_layer if isinstance(mod, LoraLinear) else mod
+
+
+# ----------------------------------------------------------------------------------------------
+class FlatLora:
+    """All LoRA parameters as ONE fp32 buffer (+ grads, Adam moments); the module parameters become views."""
+
+    def __init__(self, model, device):
+        named = [(n, p) for n, p in model.named_parameters() if "lora_" in n]
+        self.names = [n for n, _ in named]
+        total = sum(p.numel() for _, p in named)
+        self.n = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(total + 1, dtype=torch.float32, device=device)     # last slot: loss (rides the all-reduce)
+        self.m = torch.zeros(total, dtype=torch.float32, device=device)
+        self.v = torch.zeros(total, dtype=torch.float32, device=device)
+        self._off = {}
+        off = 0
+        for n, p in named:
+            k = p.numel()
+            self.params[off:off + k].copy_(p.detach().reshape(-1).to(device, torch.float32))
+            p.data = self.params[off:off + k].view(p.shape)
+            p.grad = self.grads[off:off + k].view(p.shape)
+            p.requires_grad_(True)
+            self._off[id(p)] = off
+            off += k
+
+    def offset_of(self, p):
+        return self._off[id(p)]
+
+
+class LoraTrainer:
+    """One process per GPU; `world`/`rank` follow torch.distributed when it is initialised (RCCL over xGMI)."""
+
+    def __init__(self, unet: UNet2DConditionModel, scheduler, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-5, eps=1e-8,
+                 max_train_steps=97000, lr_end=1e-7, power=1.0, device="cuda"):
+        self.unet, self.scheduler = unet, scheduler
+        self.dev = torch.device(device)
+        self.lr0, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
+        self.max_train_steps, self.lr_end, self.power = max_train_steps, lr_end, power
+        self.step_count = 0
+        self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.flat = FlatLora(unet, self.dev)
+        self._build_sites()
+        dp.broadcast_(self.flat.params, src=0)                  # DDP's initial parameter broadcast (C3), LoRA buffer only
+
+    # ---- site construction ----
+    def _build_sites(self):
+        u = self.unet
+        P = u.plan()                                             # frozen packed weights (GN params, convs, ...)
+        self.P = P
+        jobs = []
+        self.sites = {}
+
+        def attn_sites(a):
+            wq, wk, wv, wo = _base(a.to_q), _base(a.to_k), _base(a.to_v), _base(a.to_out[0])
+            c = wq.weight.shape[0]
+            bias = torch.cat([wq.bias, wk.bias, wv.bias]) if wq.bias is not None else None
+            parts = [p for p in (_lin_parts(a.to_q, 0), _lin_parts(a.to_k, c), _lin_parts(a.to_v, 2 * c)) if p]
+            qkv = LoraSite(torch.cat([wq.weight, wk.weight, wv.weight]), bias, parts, self.flat, self.dev) if parts else None
+            po = _lin_parts(a.to_out[0], 0)
+            out = LoraSite(wo.weight, wo.bias, [po], self.flat, self.dev) if po else None
+            for s in (qkv, out):
+                if s:
+                    jobs.extend(s.jobs)
+            return qkv, out
+
+        blocks = []
+        for blk in list(u.down_blocks) + [u.mid_block] + list(u.up_blocks):
+            if getattr(blk, "has_attn", True) and hasattr(blk, "attentions"):
+                blocks.extend(blk.attentions)
+        for t in blocks:
+            tb = t.transformer_blocks[0]
+            self.sites[id(tb.attn1)] = attn_sites(tb.attn1)
+            self.sites[id(tb.attn2)] = attn_sites(tb.attn2)
+        rec = b"".join(struct.pack("<qqiiiiif", *j) for j in jobs)
+        self.njobs = len(jobs)
+        self.jobs_dev = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.dev)
+
+    def repack(self):
+        ops.lora_pack(self.jobs_dev, self.njobs)
+
+    # ---- forward with tape ----
+    def _attention(self, tape, tblk_attn, Pa, hn, h_res, B, N):
+        qkv_site, out_site = self.sites[id(tblk_attn)]
+        C, H, d = Pa.c, Pa.heads, Pa.d
+        if qkv_site is not None:
+            qkv = t_lora_linear(tape, hn, qkv_site)
+        else:
+            pw = Pa.qkv
+            qkv = t_conv(tape, t_view(tape, hn, (1, 1, B * N, C)), ops.PackedW(pw.w, pw.bias, pw.N, pw.Cin))
+            qkv = t_view(tape, qkv, (B * N, 3 * C))
+        qkvT = ops.transpose_tokens(qkv.t, B, N, 3 * C)
+        o_t, lse = ops.attention_train(qkv.t, qkvT, B, N, H, d)
+        o = Var(o_t, True)
+
+        def bwd():
+            if o.g is not None:
+                acc(qkv, ops.attention_bwd(qkv.t, qkvT, o.g, o.t, lse, B, N, H, d))
+        if qkv.rg:
+            tape.record(bwd)
+        o.rg = qkv.rg
+        if out_site is not None:
+            return t_lora_linear(tape, o, out_site, res=h_res)
+        y = t_conv(tape, t_view(tape, o, (1, 1, B * N, C)), Pa.out, res=t_view(tape, h_res, (1, 1, B * N, C)))
+        return t_view(tape, y, (B * N, C))
+
+    def _transformer(self, tape, tmod, Pt, x):
+        B, H, W, C = x.shape
+        N = H * W
+        tb = tmod.transformer_blocks[0]
+        h = t_groupnorm(tape, x, Pt.gn_g, Pt.gn_b, Pt.groups, 1e-6, ACT_NONE)
+        h = t_view(tape, t_conv(tape, h, Pt.proj_in), (B * N, C))
+        h = self._attention(tape, tb.attn1, Pt.attn1, t_layernorm(tape, h, *Pt.ln[0]), h, B, N)
+        h = self._attention(tape, tb.attn2, Pt.attn2, t_layernorm(tape, h, *Pt.ln[1]), h, B, N)
+        n3 = t_layernorm(tape, h, *Pt.ln[2])
+        ff1 = Pt.__dict__.setdefault("ff1_plain", ops.PackedW(Pt.ff1.w, Pt.ff1.bias, Pt.ff1.N, Pt.ff1.Cin))   # un-fused GEGLU
+        hp = t_view(tape, t_conv(tape, t_view(tape, n3, (1, 1, B * N, C)), ff1), (B * N, 8 * C))
+        g = Var(ops.geglu_fwd(hp.t), hp.rg)
+        if hp.rg:
+            tape.record(lambda: acc(hp, ops.geglu_bwd(hp.t, g.g)) if g.g is not None else None)
+        h4 = t_view(tape, h, (1, 1, B * N, C))
+        h = t_conv(tape, t_view(tape, g, (1, 1, B * N, 4 * C)), Pt.ff2, res=h4)
+        return t_conv(tape, t_view(tape, h, (B, H, W, C)), Pt.proj_out, res=x)
+
+    @staticmethod
+    def _resnet(tape, Pr, x, x2, rowbias, ld):
+        h = t_groupnorm(tape, x, Pr.g1, Pr.b1, Pr.groups, Pr.eps, ACT_SILU, x2=x2)
+        h = t_conv(tape, h, Pr.conv1, pad=(1, 1), rowbias=rowbias[:, Pr.temb_off:], rowbias_ld=ld)
+        h = t_groupnorm(tape, h, Pr.g2, Pr.b2, Pr.groups, Pr.eps, ACT_SILU)
+        xs = t_conv(tape, x, Pr.shortcut, x2=x2) if Pr.shortcut is not None else x
+        return t_conv(tape, h, Pr.conv2, pad=(1, 1), res=xs)
+
+    def forward(self, tape, x_in, t_dev, cls_bf16):
+        u, P = self.unet, self.P
+        cfg = u.cfg
+        b, H, W, _ = x_in.shape
+        boc = cfg["block_out_channels"]
+        ted = boc[0] * 4
+        groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+        factor = 2 ** u.num_upsamplers
+        fus = (H % factor != 0) or (W % factor != 0)
+        temb = ops.timestep_embedding(t_dev, b, boc[0])
+        e1 = ops.linear(temb, P.te1, out_act=ACT_SILU)
+        semb = torch.empty(b, 2 * ted, dtype=torch.bfloat16, device=x_in.device)
+        ops.linear(e1, P.te2, out_act=ACT_SILU, out=semb, out_ld=2 * ted)
+        ops.linear(cls_bf16, P.cls, out_act=ACT_SILU, out=semb[:, ted:], out_ld=2 * ted)
+        rowbias = ops.linear(semb, P.temb_all, out_f32=True)
+        ld = P.temb_total
+
+        h = Var(ops.conv(x_in, P.conv_in, pad=(1, 1)))
+        skips = [h]
+        for blk, Pb in zip(u.down_blocks, P.down):
+            for i, r in enumerate(Pb.resnets):
+                h = self._resnet(tape, r, h, None, rowbias, ld)
+                if Pb.attns is not None:
+                    h = self._transformer(tape, blk.attentions[i], Pb.attns[i], h)
+                skips.append(h)
+            if Pb.down is not None:
+                h = t_conv(tape, h, Pb.down, stride=(2, 2), pad=(1, 1))
+                skips.append(h)
+        h = self._resnet(tape, P.mid.resnets[0], h, None, rowbias, ld)
+        h = self._transformer(tape, u.mid_block.attentions[0], P.mid.attns[0], h)
+        h = self._resnet(tape, P.mid.resnets[1], h, None, rowbias, ld)
+        for blk, Pb in zip(u.up_blocks, P.up):
+            for i, r in enumerate(Pb.resnets):
+                h = self._resnet(tape, r, h, skips.pop(), rowbias, ld)
+                if Pb.attns is not None:
+                    h = self._transformer(tape, blk.attentions[i], Pb.attns[i], h)
+            if Pb.up is not None:
+                size = (skips[-1].shape[1], skips[-1].shape[2]) if fus else (h.shape[1] * 2, h.shape[2] * 2)
+                h = t_conv(tape, h, Pb.up, pad=(1, 1), up_size=size)
+        h = t_groupnorm(tape, h, P.gn_out[0], P.gn_out[1], groups, eps, ACT_SILU)
+        return t_conv(tape, h, P.conv_out, pad=(1, 1), out_f32=True)
+
+    # ---- schedule / step ----
+    def lr(self, step):
+        """diffusers get_scheduler("polynomial") with 0 warm-up [REF train:438-443]."""
+        if step > self.max_train_steps:
+            return self.lr_end
+        return (self.lr0 - self.lr_end) * (1 - step / self.max_train_steps) ** self.power + self.lr_end
+
+    def loss_and_grads(self, latents, noise, timesteps, prompt_embeds):
+        """Fills the flat gradient buffer (sum over this rank's batch-mean loss); returns the device loss scalar view."""
+        f = self.flat
+        self.repack()
+        f.grads.zero_()
+        noisy = self.scheduler.add_noise(latents.to(self.dev, torch.float32), noise.to(self.dev, torch.float32),
+                                         timesteps.to(self.dev))
+        x_in = ops.nchw_to_nhwc(noisy)
+        tgt = ops.nchw_to_nhwc(noise.to(self.dev, torch.float32).contiguous(), out_f32=True)
+        t_dev = timesteps.to(self.dev, torch.float32).contiguous()
+        cls = ops.f32_to_bf16(prompt_embeds.to(self.dev, torch.float32).contiguous())
+        tape = Tape()
+        pred = self.forward(tape, x_in, t_dev, cls)
+        pred.g = ops.mse_grad(pred.t, tgt, f.grads[f.n:])
+        tape.backward()
+        return f.grads[f.n:]
+
+    def step(self, latents, noise, timesteps, prompt_embeds):
+        """One optimisation step; returns the (all-rank mean) loss as a device tensor."""
+        f = self.flat
+        loss = self.loss_and_grads(latents, noise, timesteps, prompt_embeds)
+        if self.dist and self.world > 1:
+            self.dist.all_reduce(f.grads)                         # ONE flat all-reduce: every LoRA grad + the loss slot
+        self.step_count += 1
+        ops.adamw_flat(f.params, f.grads, f.m, f.v, self.lr(self.step_count - 1), self.betas[0], self.betas[1], self.eps,
+                       self.wd, self.step_count, grad_scale=1.0 / self.world)
+        return loss / self.world
