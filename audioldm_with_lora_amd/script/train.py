@@ -1,0 +1,92 @@
+"""LoRA fine-tuning driver -- MI355X mirror of  script/train/train_audioldm_lora.py:main  [REF train:324-626].
+
+Same structure and the same default hyper-parameters as the reference's hard-coded literals:
+base model cvssp/audioldm-s-full-v2, LoRA r=2 / alpha=2 / gaussian init on to_q,to_v [REF train:378-383], AdamW lr 1e-5
+betas (0.9, 0.999) wd 1e-5 eps 1e-8 [REF train:396-403], batch 2 per process [REF train:406], polynomial LR with no
+warm-up [REF train:438-443], max 97 000 steps, checkpoint every 19 400 steps [REF train:410-411,574-576].
+One process per GPU (torchrun); gradients are all-reduced as ONE flat buffer over RCCL.
+
+Inputs start at the north_star boundary: VAE latents [B, 8, 256, 16] and L2-normalised CLAP prompt embeddings [B, 512].
+`--latents-file` loads a .pt dict {latents, prompt_embeds}; without it the driver trains on synthetic tensors (no
+datasets or checkpoints are available offline).  The dataset / mel front end / CLAP metrics of the reference are out of
+scope.
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m audioldm_with_lora_amd.script.train \
+        --max-train-steps 100
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+from .. import dp
+from ..lora import LoraConfig, get_peft_model
+from ..scheduler import DDIMScheduler
+from ..training import LoraTrainer
+from ..unet import UNet2DConditionModel
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model-dir", default=None, help="local diffusers-format directory of cvssp/audioldm-s-full-v2")
+    ap.add_argument("--latents-file", default=None)
+    ap.add_argument("--output-dir", default="data/LoRA_weight/r2_alpha2")
+    ap.add_argument("--rank", type=int, default=2)
+    ap.add_argument("--lora-alpha", type=int, default=2)
+    ap.add_argument("--target-modules", default="to_q,to_v")
+    ap.add_argument("--learning-rate", type=float, default=1.0e-5)
+    ap.add_argument("--weight-decay", type=float, default=1e-5)
+    ap.add_argument("--train-batch-size", type=int, default=2)
+    ap.add_argument("--max-train-steps", type=int, default=97000)
+    ap.add_argument("--checkpointing-steps", type=int, default=9700 * 2)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    accelerator = dp.Accelerator(gradient_accumulation_steps=1, mixed_precision=None)
+    device = accelerator.device
+    torch.manual_seed(1234)                                       # identical base weights on every rank
+    if args.model_dir:
+        unet = UNet2DConditionModel.from_pretrained(args.model_dir, subfolder="unet")
+        noise_scheduler = DDIMScheduler.from_pretrained(args.model_dir, subfolder="scheduler")
+    else:
+        unet, noise_scheduler = UNet2DConditionModel(), DDIMScheduler()
+    unet.requires_grad_(False)
+    cfg = LoraConfig(r=args.rank, lora_alpha=args.lora_alpha, init_lora_weights="gaussian",
+                     target_modules=args.target_modules.split(","))
+    peft_unet = get_peft_model(unet, cfg)
+    unet.to(device)
+    trainer = LoraTrainer(unet, noise_scheduler, lr=args.learning_rate, betas=(0.9, 0.999), weight_decay=args.weight_decay,
+                          eps=1e-08, max_train_steps=args.max_train_steps, device=device)
+
+    data = torch.load(args.latents_file) if args.latents_file else None
+    g = torch.Generator().manual_seed(args.seed + 1000 * accelerator.process_index)      # per-rank noise / timesteps
+    B = args.train_batch_size
+    t0, train_loss = time.time(), 0.0
+    for global_step in range(1, args.max_train_steps + 1):
+        if data is not None:
+            idx = torch.randint(0, data["latents"].shape[0], (B,), generator=g)
+            latents, prompt_embeds = data["latents"][idx], data["prompt_embeds"][idx]
+        else:
+            latents = torch.randn(B, 8, 256, 16, generator=g) * 0.9228
+            prompt_embeds = torch.nn.functional.normalize(torch.randn(B, unet.cfg["class_embed_input_dim"], generator=g), dim=-1)
+        noise = torch.randn(latents.shape, generator=g)
+        timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (B,), generator=g).long()
+        loss = trainer.step(latents, noise, timesteps, prompt_embeds)
+        if global_step % 10 == 0 or global_step == args.max_train_steps:
+            train_loss = float(loss)
+            if accelerator.is_main_process:
+                print(json.dumps({"step": global_step, "train_loss": train_loss, "lr": trainer.lr(global_step),
+                                  "clips_per_sec": global_step * B * accelerator.num_processes / (time.time() - t0)}), flush=True)
+        if global_step % args.checkpointing_steps == 0 and accelerator.is_main_process:
+            accelerator.save_state(os.path.join(args.output_dir, f"checkpoint-{global_step}"), trainer)
+    accelerator.wait_for_everyone()
+    if accelerator.is_main_process:
+        accelerator.save_state(os.path.join(args.output_dir, f"checkpoint-{args.max_train_steps}"), trainer)
+    accelerator.end_training()
+    return train_loss
+
+
+if __name__ == "__main__":
+    main()

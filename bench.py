@@ -105,6 +105,53 @@ def cpu_baseline(batch, height, width, rank_lora, max_seconds=30.0):
                       f"after 1 warm-up; median {med:.2f} s/step"}
 
 
+def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
+    """Config 3/4: LoRA fine-tune step (add_noise -> UNet fwd -> MSE -> bwd -> flat all-reduce -> AdamW) on synthetic
+    10.24 s mel latents [8, 8, 256, 16] per GPU; clips/s = world * batch / step time."""
+    from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    from audioldm_with_lora_amd.training import LoraTrainer
+    from audioldm_with_lora_amd.unet import UNet2DConditionModel
+    import torch.distributed as dist
+    torch.manual_seed(1234)
+    unet = UNet2DConditionModel()
+    get_peft_model(unet, LoraConfig(r=rank_lora, lora_alpha=rank_lora, init_lora_weights="gaussian",
+                                    target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    unet.cuda()
+    tr = LoraTrainer(unet, DDIMScheduler(), lr=1e-5, weight_decay=1e-5, max_train_steps=97000)
+    g = torch.Generator().manual_seed(5 + rank)
+    lat = (torch.randn(batch, 8, 256, 16, generator=g) * 0.9228).cuda()
+    noise = torch.randn(batch, 8, 256, 16, generator=g).cuda()
+    t = torch.randint(0, 1000, (batch,), generator=g).cuda()
+    emb = torch.nn.functional.normalize(torch.randn(batch, 512, generator=g), dim=-1).cuda()
+    for _ in range(warmup):
+        tr.step(lat, noise, t, emb)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(lat, noise, t, emb)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+    del tr, unet
+    torch.cuda.empty_cache()
+    return {"metric": "lora_train_clips_per_sec", "value": round(world * batch * steps / dt, 3), "unit": "10.24s-clips/s",
+            "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "per_gpu_batch": batch, "lora_rank": rank_lora,
+            "lora_params": tr_params(rank_lora), "final_loss": round(float(loss), 5),
+            "collective": "1 flat fp32 all-reduce/step (RCCL)" if world > 1 else "none"}
+
+
+def tr_params(r):
+    return 112640 * r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +161,7 @@ def main():
     ap.add_argument("--rank", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the short LoRA-training measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--fine", action="store_true", help="print the per-kernel-per-shape table to stderr")
     args = ap.parse_args()
@@ -163,6 +211,11 @@ def main():
         dt = float(tmax.item())
     assert torch.isfinite(eng.x).all(), "latents diverged"
 
+    train = None
+    if not args.no_train:
+        eng.graph = None
+        torch.cuda.empty_cache()
+        train = bench_train(world, rank)
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
         prof = kernel_profile(eng)
@@ -193,6 +246,8 @@ def main():
                        "sample_steps_per_sec": round(world * args.steps * args.batch / dt, 2)},
             "roofline": roofline,
         }
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, H, W, args.rank)
         print(json.dumps(out))

@@ -1,0 +1,79 @@
+"""Multi-process data parallelism on CPU (gloo, world_size 2): the flat-buffer all-reduce of the DP runtime gives the
+same LoRA gradients / update as a single process on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_lora_grads(batch_slice, seed=0):
+    """Oracle (CPU autograd) LoRA gradients + loss on a slice of a fixed global batch."""
+    from oracle import configs
+    from oracle import lora as olora
+    from oracle.ddim import DDIMScheduler
+    from oracle.unet import UNet2DConditionModel
+    torch.manual_seed(seed)
+    u = UNet2DConditionModel(**configs.tiny_unet())
+    pm = olora.get_peft_model(u, olora.LoraConfig(r=2, lora_alpha=2, target_modules=["to_q", "to_v"], init_lora_weights="gaussian"))
+    g = torch.Generator().manual_seed(seed + 1)
+    for n, p in pm.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    lat = torch.randn(4, 8, 8, 8, generator=g)
+    noise = torch.randn(4, 8, 8, 8, generator=g)
+    t = torch.randint(0, 1000, (4,), generator=g)
+    emb = torch.nn.functional.normalize(torch.randn(4, 64, generator=g), dim=-1)
+    sl = batch_slice
+    s = DDIMScheduler()
+    pred = pm(s.add_noise(lat[sl], noise[sl], t[sl]), t[sl], class_labels=emb[sl])[0]
+    loss = torch.nn.functional.mse_loss(pred, noise[sl])
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for n, p in pm.named_parameters() if p.requires_grad] + [loss.detach().reshape(1)])
+    return flat
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from audioldm_with_lora_amd import dp
+    assert dp.init_from_env(backend="gloo") == world
+    acc = dp.Accelerator()
+    assert acc.num_processes == world and acc.process_index == rank and acc.is_main_process == (rank == 0)
+    flat = _flat_lora_grads(dp.shard_batch(4, rank, world))
+    params = torch.full((8,), float(rank))
+    dp.broadcast_(params, src=0)
+    assert torch.all(params == 0)                          # C3: rank 0's LoRA parameters everywhere
+    dp.flat_allreduce_mean_(flat)                          # C1 + C2: one collective for all grads + the loss slot
+    gathered = acc.gather(flat[-1])
+    assert gathered.shape == (world,)
+    acc.wait_for_everyone()
+    if rank == 0:
+        torch.save(flat, out)
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_equals_single_process_gradient(tmp_path):
+    out = str(tmp_path / "flat.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    want = _flat_lora_grads(slice(0, 4))
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6)
+
+
+def test_single_process_helpers_are_noops():
+    from audioldm_with_lora_amd import dp
+    b = torch.arange(4.0)
+    assert torch.equal(dp.flat_allreduce_mean_(b.clone()), b)
+    assert dp.shard_batch(64, 3, 8) == slice(24, 32)
