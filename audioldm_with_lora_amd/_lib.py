@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaldm_hip.so")
+LIB_PATH = os.environ.get("ALDM_LIB") or os.path.join(_HERE, "libaldm_hip.so")   # ALDM_LIB: diagnostic builds only
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 OUT_BF16, OUT_F32 = 0, 1
@@ -42,6 +42,7 @@ class IgemmArgs(C.Structure):
         ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_ld", C.c_int), ("vt_batch_stride", C.c_longlong),
         ("splits", C.c_int), ("workspace", C.c_void_p),
         ("tile", C.c_int),
+        ("ring", C.c_int),
     ]
 
 

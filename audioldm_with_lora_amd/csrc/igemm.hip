@@ -5,10 +5,10 @@
 using namespace aldm_igemm_detail;
 
 // one launcher per tile shape, defined in igemm_t*.hip
-int aldm_launch_tile_128x128(const IgemmDev& d, int Rp, bool vt, hipStream_t st);
-int aldm_launch_tile_128x64(const IgemmDev& d, int Rp, bool vt, hipStream_t st);
-int aldm_launch_tile_64x128(const IgemmDev& d, int Rp, bool vt, hipStream_t st);
-int aldm_launch_tile_64x64(const IgemmDev& d, int Rp, bool vt, hipStream_t st);
+int aldm_launch_tile_128x128(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_128x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_64x128(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_64x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 
 static int pick_tile(int M, int N) {
   auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
@@ -41,6 +41,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
+  ALDM_CHECK_ARG(p->ring == 0 || (p->ring >= 2 && p->ring <= 4), "igemm: ring must be 0 (auto) or 2..4");
   ALDM_CHECK_ARG(p->in_dilate == 0 || (p->in_dilate == 2 && p->UH == 0), "igemm: in_dilate must be 0 or 2 (and excludes UH/UW)");
 
   IgemmDev d;
@@ -74,6 +75,11 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.w_bytes = (unsigned)wb;
     d.la_bytes = (unsigned)lb;
     d.lb_bytes = (unsigned)(2ull * p->Cout * p->Rp);
+#ifdef ALDM_DIAG
+    d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer
+#else
+    d.diag = nullptr;
+#endif
   }
   hipStream_t st = (hipStream_t)stream;
 
@@ -81,10 +87,10 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   const bool vt = p->vt != nullptr;
   int rc;
   switch (tile) {
-    case ALDM_TILE_128x128: rc = aldm_launch_tile_128x128(d, p->Rp, vt, st); break;
-    case ALDM_TILE_128x64: rc = aldm_launch_tile_128x64(d, p->Rp, vt, st); break;
-    case ALDM_TILE_64x128: rc = aldm_launch_tile_64x128(d, p->Rp, vt, st); break;
-    case ALDM_TILE_64x64: rc = aldm_launch_tile_64x64(d, p->Rp, vt, st); break;
+    case ALDM_TILE_128x128: rc = aldm_launch_tile_128x128(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_128x64: rc = aldm_launch_tile_128x64(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_64x128: rc = aldm_launch_tile_64x128(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_64x64: rc = aldm_launch_tile_64x64(d, p->Rp, vt, p->ring, st); break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;
   }
   if (rc != ALDM_OK) return rc;

@@ -42,6 +42,7 @@ struct IgemmDev {
   int splits, kt_per_split, nkt;
   int tiles_n;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
+  unsigned long long* diag;   // diagnostic builds only
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -117,72 +118,184 @@ __device__ __forceinline__ void add_bias4(const IgemmDev& p, int m, int n, float
   }
 }
 
-// ---- shared epilogue: acc[MI][NI] 16x16 tiles of one wave -> bias / GEGLU / act / residual / store --------
-template <int MI, int NI, bool VT>
-__device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], const bool (&vt_tile)[NI],
-                                               int wm0, int wn0, int lrow, int lq, int split) {
-  if (p.splits > 1) {
+// ---- shared epilogue ---------------------------------------------------------------------------------------------
+// The accumulators go through LDS (the K-loop buffers are free by then): every wave drops its 16x16 tiles into one
+// fp32 [BM][BN+4] image (or its transpose for V^T tiles), then the whole workgroup walks that image in 8-column groups.
+// One compact copy of the bias / GEGLU / activation / residual / store code serves all tiles (the fully unrolled
+// per-tile form was ~20k instructions of cold straight-line code -- an instruction-cache disaster that cost more than
+// the K loop itself), and global stores become full 16-byte row segments.
+__device__ __forceinline__ void epi8(const IgemmDev& p, int m, int n, int ncols, float* v) {
+  // v[0..7]: output columns n..n+7 of output row m, bias already added
+  const int b = m / p.OHW;
+  const int pix = m - b * p.OHW;
+  const long long row = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
+  const bool vec = (n + 7 < ncols) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
+  if (p.out_act) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = wm0 + i * 16 + lrow;
-      if (m >= p.M) continue;
+    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], p.out_act, p.out_slope);
+  }
+  if (p.res) {
+    if (vec) {
+      const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.res + row + n);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = wn0 + j * 16 + lq * 4;
-        if (n >= p.N) continue;
-        float* o = p.ws + ((long long)split * p.M + m) * p.N + n;
-        *reinterpret_cast<f32x4*>(o) = acc[i][j];
+      for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+    } else {
+      for (int j = 0; j < 8; ++j) if (n + j < ncols) v[j] += (float)p.res[row + n + j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+  if (p.res2) {
+    if (vec) {
+      const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.res2 + row + n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+    } else {
+      for (int j = 0; j < 8; ++j) if (n + j < ncols) v[j] += (float)p.res2[row + n + j];
+    }
+  }
+  if (p.out2) {
+    bf16* o2 = p.out2 + row + n;
+    if (vec) {
+      bf16x8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = (bf16)apply_act(v[j], p.post_act, p.post_slope);
+      *reinterpret_cast<bf16x8*>(o2) = t;
+    } else {
+      for (int j = 0; j < 8; ++j) if (n + j < ncols) o2[j] = (bf16)apply_act(v[j], p.post_act, p.post_slope);
+    }
+  } else if (p.post_act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], p.post_act, p.post_slope);
+  }
+  if (p.out_f32) {
+    float* o = reinterpret_cast<float*>(p.out) + row + n;
+    if (vec) {
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      for (int j = 0; j < 8; ++j) if (n + j < ncols) o[j] = v[j];
+    }
+  } else {
+    bf16* o = reinterpret_cast<bf16*>(p.out) + row + n;
+    if (vec) {
+      bf16x8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = (bf16)v[j];
+      *reinterpret_cast<bf16x8*>(o) = t;
+    } else {
+      for (int j = 0; j < 8; ++j) if (n + j < ncols) o[j] = (bf16)v[j];
+    }
+  }
+}
+
+template <int BM, int BN>
+struct EpiCfg {
+  static constexpr int LD = BN + 4;                         // fp32 row stride of the normal image
+  static constexpr int LDT = BM + 4;                        // row stride of the transposed (V^T) image
+  static constexpr int BYTES = (BM * LD > BN * LDT ? BM * LD : BN * LDT) * 4;
+};
+
+template <int BM, int BN, int MI, int NI, bool VT>
+__device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], char* smem, bool vt_wg, int m0,
+                                               int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid) {
+  using E = EpiCfg<BM, BN>;
+  float* Cs = reinterpret_cast<float*>(smem);
+  __syncthreads();                                           // every wave is done with the K-loop images
+  if (VT && vt_wg) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)   // un-swapped MFMA: lane holds 4 consecutive pixels of channel column lrow
+        *reinterpret_cast<f32x4*>(Cs + (wn_off + j * 16 + lrow) * E::LDT + wm_off + i * 16 + lq * 4) = acc[i][j];
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)   // swapped MFMA: lane holds 4 consecutive channels of pixel row lrow
+        *reinterpret_cast<f32x4*>(Cs + (wm_off + i * 16 + lrow) * E::LD + wn_off + j * 16 + lq * 4) = acc[i][j];
+  }
+  __syncthreads();
+
+  if (VT && vt_wg) {
+    // rows of the image are channels n, columns are pixels: vt[b][n - col0][pix .. pix+7]
+    for (int g = tid; g < BN * (BM / 8); g += THREADS) {
+      const int rn = g / (BM / 8), cm = (g - rn * (BM / 8)) * 8;
+      const int n = n0 + rn, m = m0 + cm;
+      if (n >= p.N || m >= p.M) continue;
+      const float bb = p.bias ? p.bias[n] : 0.f;
+      const float* src = Cs + rn * E::LDT + cm;
+      const int b = m / p.OHW, pix = m - b * p.OHW;
+      bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
+      if (m + 7 < p.M && pix + 7 < p.OHW && ((p.vt_ld & 7) == 0) && ((pix & 7) == 0) && ((p.vt_bs & 7) == 0)) {
+        bf16x8 t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (bf16)(src[q] + bb);
+        *reinterpret_cast<bf16x8*>(o) = t;
+      } else {
+        for (int q = 0; q < 8; ++q) {
+          const int mq = m + q;
+          if (mq >= p.M) break;
+          const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
+          p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(src[q] + bb);
+        }
       }
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      if (VT && vt_tile[j]) {
-        // lane holds 4 consecutive pixels (rows) of channel n: transposed 8-byte store
-        const int n = wn0 + j * 16 + lrow;
-        const int m = wm0 + i * 16 + lq * 4;
-        if (n >= p.N || m >= p.M) continue;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        const float bb = p.bias ? p.bias[n] : 0.f;
-        const int b = m / p.OHW, pix = m - b * p.OHW;
-        bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
-        if (m + 3 < p.M && pix + 3 < p.OHW && ((p.vt_ld & 3) == 0) && ((pix & 3) == 0)) {
-          *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16)(v[0] + bb), (bf16)(v[1] + bb), (bf16)(v[2] + bb), (bf16)(v[3] + bb)};
-        } else {
-          for (int q = 0; q < 4; ++q) {
-            const int mq = m + q;
-            if (mq >= p.M) break;
-            const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
-            p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(v[q] + bb);
-          }
-        }
-        continue;
-      }
-      const int m = wm0 + i * 16 + lrow;
-      const int n = wn0 + j * 16 + lq * 4;
+  if (p.splits > 1) {
+    for (int g = tid; g < BM * (BN / 8); g += THREADS) {
+      const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
+      const int m = m0 + r, n = n0 + c;
       if (m >= p.M || n >= p.N) continue;
-      if (p.geglu) {
-        if (j & 1) continue;  // gate tile is consumed together with its value tile
-        float val[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        const int jg = (j + 1 < NI) ? j + 1 : j;
-        float gate[4] = {acc[i][jg][0], acc[i][jg][1], acc[i][jg][2], acc[i][jg][3]};
-        if (p.bias) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { val[q] += p.bias[n + q]; gate[q] += p.bias[n + 16 + q]; }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) val[q] *= gelu_erf_f(gate[q]);
-        const int nout = ((n >> 5) << 4) + (n & 15);
-        finish_store4(p, m, nout, p.N >> 1, val);
+      float* o = p.ws + ((long long)split * p.M + m) * p.N + n;
+      const float* src = Cs + r * E::LD + c;
+      if (n + 7 < p.N) {
+        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(src + 4);
       } else {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        add_bias4(p, m, n, v);
-        finish_store4(p, m, n, p.N, v);
+        for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = src[q];
       }
     }
+    return;
+  }
+  if (p.geglu) {
+    // image columns come in blocks of (16 value | 16 gate); 8 output columns = 8 values and their 8 gates
+    for (int g = tid; g < BM * (BN / 16); g += THREADS) {
+      const int r = g / (BN / 16), jo = (g - r * (BN / 16)) * 8;        // jo: output column inside the tile
+      const int cv = ((jo >> 4) << 5) + (jo & 15);                       // value column inside the tile
+      const int m = m0 + r, nv = n0 + cv;
+      if (m >= p.M || nv >= p.N) continue;
+      const float* src = Cs + r * E::LD + cv;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float val = src[q], gate = src[16 + q];
+        if (p.bias) { val += p.bias[nv + q]; gate += p.bias[nv + 16 + q]; }
+        v[q] = val * gelu_erf_f(gate);
+      }
+      epi8(p, m, (n0 >> 1) + jo, p.N >> 1, v);
+    }
+    return;
+  }
+  for (int g = tid; g < BM * (BN / 8); g += THREADS) {
+    const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
+    const int m = m0 + r, n = n0 + c;
+    if (m >= p.M || n >= p.N) continue;
+    const float* src = Cs + r * E::LD + c;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = src[q];
+    if (p.bias) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (n + q < p.N) v[q] += p.bias[n + q];
+    }
+    if (p.rowbias) {
+      const float* rb = p.rowbias + (long long)(m / p.OHW) * p.rowbias_ld;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (n + q < p.N) v[q] += rb[n + q];
+    }
+    epi8(p, m, n, p.N, v);
   }
 }
 
@@ -395,7 +508,12 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
     for (int ks = 0; ks < RP / 32; ++ks) mma_step(0, ks, false);
   }
 
-  igemm_epilogue<MI, NI, VT>(p, acc, vt_tile, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lrow, lq, split);
+  {
+    bool any_vt = false;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) any_vt = any_vt || vt_tile[j];
+    igemm_epilogue<BM, BN, MI, NI, VT>(p, acc, smem, any_vt, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid);
+  }
 }
 
 // ---- pipelined kernel: LDS-DMA (buffer_load ... lds) ring, counted vmcnt, one raw barrier per K-tile -------
@@ -441,7 +559,16 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  // XCD-aware tile order: hardware deals workgroups round-robin over the 8 XCDs (blocks b, b+8, ... share an L2), so
+  // give each XCD a CONTIGUOUS range of output tiles -- its slice of the activation image (plus halo) then stays in
+  // that XCD's 4 MiB L2 instead of every L2 streaming the whole image.  Bijective for any grid size; speed only.
+  int wgid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = wgid / p.tiles_n, tile_n = wgid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.z;
   const int kt0 = split * p.kt_per_split;
@@ -611,19 +738,47 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   }
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(kt0 + s, s);
+#ifdef ALDM_DIAG   // diagnostic build only (tools/diag_igemm.py): per-wave cycle split of the main loop
+  unsigned long long dg_wait = 0, dg_bar = 0, dg_issue = 0, dg_mma = 0;
+#define ALDM_STAMP(var) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; }
+#endif
   auto main_loop = [&](auto vtf) {
     int st = 0, st_fill = D;
     for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef ALDM_DIAG
+      unsigned long long t0, t1, t2, t3, t4;
+      ALDM_STAMP(t0)
+#endif
       wait_vmcnt<(D - 1) * L>();
+#ifdef ALDM_DIAG
+      ALDM_STAMP(t1)
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef ALDM_DIAG
+      ALDM_STAMP(t2)
+#endif
       issue(kt + D, st_fill);
+#ifdef ALDM_DIAG
+      ALDM_STAMP(t3)
+#endif
       mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 0, true);
       mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 1, true);
+#ifdef ALDM_DIAG
+      asm volatile("s_nop 0" :: "v"(acc[0][0][0]));
+      ALDM_STAMP(t4)
+      dg_wait += t1 - t0; dg_bar += t2 - t1; dg_issue += t3 - t2; dg_mma += t4 - t3;
+#endif
       st = (st + 1 == S) ? 0 : st + 1;
       st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
     }
   };
   if (VT && vt_wg) main_loop(std::true_type{}); else main_loop(std::false_type{});
+#ifdef ALDM_DIAG
+  if (p.diag && lane == 0) {
+    unsigned long long* o = p.diag + ((long long)(blockIdx.x + gridDim.x * blockIdx.z) * 4 + wave) * 4;
+    o[0] = dg_wait; o[1] = dg_bar; o[2] = dg_issue; o[3] = dg_mma;
+  }
+#endif
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -648,7 +803,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
       else mma_step(std::false_type{}, smem, LBs, ks, false);
     }
   }
-  igemm_epilogue<MI, NI, VT>(p, acc, vt_tile, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lrow, lq, split);
+  igemm_epilogue<BM, BN, MI, NI, VT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid);
 #endif
 }
 
@@ -692,7 +847,8 @@ static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev
 template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
 int launch_cfg(const IgemmDev& d, hipStream_t st) {
   // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
-  constexpr size_t lds = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
+  constexpr size_t lds_loop = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
+  constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static bool attr_done = false;   // one-time, idempotent; races are benign
   void (*kern)(const IgemmDev);
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
@@ -713,29 +869,32 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   return aldm_launch_status("igemm");
 }
 
-// S0 = ring depth without LoRA, SL = with LoRA (the LoRA rows + B tile cost LDS; SL is chosen so that the
-// workgroups-per-CU count does not drop, which matters more than ring depth for the short-K projection GEMMs)
-template <int BM, int BN, int WM, int WN, int S0, int SL>
+template <int BM, int BN, int WM, int WN, int S>
 int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
   if (vt) {
-    if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S0>(d, st);
-    if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, SL>(d, st);
-    return launch_cfg<BM, BN, WM, WN, 64, true, SL>(d, st);
+    if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S>(d, st);
+    if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S>(d, st);
+    return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
   }
-  if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S0>(d, st);
-  if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, SL>(d, st);
-  return launch_cfg<BM, BN, WM, WN, 64, false, SL>(d, st);
+  if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S>(d, st);
+  if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S>(d, st);
+  return launch_cfg<BM, BN, WM, WN, 64, false, S>(d, st);
 }
 
+// S0 / SL = default ring depth without / with LoRA (the LoRA rows + B tile cost LDS; SL is chosen so that the
+// workgroups-per-CU count does not drop, which matters more than ring depth for the short-K projection GEMMs).
+// `ring` (2..4) overrides it (tuning: tools/bench_igemm.py --ring).
 template <int BM, int BN, int WM, int WN, int S0, int SL>
-int launch_tile(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
+int launch_tile(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   // LDS-DMA ring needs a scalar K cursor (64-channel K-tiles inside one tap of one source), no gather-side
   // activation and < 2 GiB activations (32-bit buffer offsets, 0x80000000 = "padded tap").
   const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u &&
                     d.x2_bytes < 0x80000000u;
-  if (!fast) return launch_rp<BM, BN, WM, WN, 0, 0>(d, Rp, vt, st);
-  return launch_rp<BM, BN, WM, WN, S0, SL>(d, Rp, vt, st);
+  if (!fast) return launch_rp<BM, BN, WM, WN, 0>(d, Rp, vt, st);
+  const int S = ring ? ring : (Rp ? SL : S0);
+  if (S == 2) return launch_rp<BM, BN, WM, WN, 2>(d, Rp, vt, st);
+  if (S == 3) return launch_rp<BM, BN, WM, WN, 3>(d, Rp, vt, st);
+  return launch_rp<BM, BN, WM, WN, 4>(d, Rp, vt, st);
 }
-
 
 }  // namespace aldm_igemm_detail

@@ -1,5 +1,5 @@
 // Instantiates the implicit-GEMM kernels for the 64x128 workgroup tile (see igemm_core.h).
 #include "igemm_core.h"
-int aldm_launch_tile_64x128(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, hipStream_t st) {
-  return aldm_igemm_detail::launch_tile<64, 128, 2, 2, 3, 2>(d, Rp, vt, st);
+int aldm_launch_tile_64x128(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
+  return aldm_igemm_detail::launch_tile<64, 128, 2, 2, 3, 2>(d, Rp, vt, ring, st);
 }

@@ -164,7 +164,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0):
+         splits=None, tile=0, ring=0):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2])."""
     _require_gpu(x)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
@@ -233,6 +233,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if tile == 0:
         tile = _lib.TILE_64x64 if pw.Rp else pick_tile(M, pw.N)      # LoRA GEMMs are short-K: favour many workgroups
     a.tile = tile
+    a.ring = ring if ring else (2 if ktiles <= 24 else 3)     # sweep: short K loops want occupancy, deep ones a deeper ring
     ktot = KH * KW * pw.Cin
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)
     nbytes = 2.0 * (B * IH * IW * pw.Cin + pw.N * ktot + M * ncols)

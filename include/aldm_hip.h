@@ -84,6 +84,7 @@ typedef struct {
   /* split-K */
   int splits;  float* workspace;                    /* [splits][M][Cout] fp32 when splits > 1 */
   int tile;                 /* 0 = auto, else ALDM_TILE_* */
+  int ring;                 /* 0 = auto, else LDS-DMA ring depth 2..4 (tuning) */
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,

@@ -36,11 +36,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiles", default="0,1,3,2")
     ap.add_argument("--splits", default="0")
+    ap.add_argument("--ring", default="0")
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(",")]
     splits = [int(t) for t in a.splits.split(",")]
+    rings = [int(t) for t in a.ring.split(",")]
     dev = "cuda"
     tot = {}
     for name, B, H, W, c1, c2, co, k, st, up in SHAPES:
@@ -53,8 +55,9 @@ def main():
         pad = (k // 2, k // 2)
         line = f"{name:34s}"
         for t in tiles:
-            for sp in splits:
-                kw = dict(x2=x2, stride=(st, st), pad=pad, up_size=up, tile=t, splits=(None if sp == 0 else sp))
+            for sp in [(a_, b_) for a_ in splits for b_ in rings]:
+                sp, rg = sp
+                kw = dict(x2=x2, stride=(st, st), pad=pad, up_size=up, tile=t, splits=(None if sp == 0 else sp), ring=rg)
                 y = ops.conv(x, pw, **kw)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,8 +69,8 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / a.reps
                 M = y.shape[0] * y.shape[1] * y.shape[2]
                 fl = 2.0 * M * co * k * k * (c1 + c2)
-                line += f" | t{t}s{sp}: {us:7.1f}us {fl / us / 1e6:6.0f}TF"
-                tot[(t, sp)] = tot.get((t, sp), 0.0) + us
+                line += f" | t{t}s{sp}r{rg}: {us:7.1f}us {fl / us / 1e6:6.0f}TF"
+                tot[(t, sp, rg)] = tot.get((t, sp, rg), 0.0) + us
         print(line, flush=True)
     print("sum us:", {k: round(v, 1) for k, v in tot.items()})
     if a.only and "qkv" not in a.only:
