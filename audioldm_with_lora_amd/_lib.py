@@ -26,6 +26,7 @@ class IgemmArgs(C.Structure):
         ("pad_h", C.c_int), ("pad_w", C.c_int), ("dil_h", C.c_int), ("dil_w", C.c_int),
         ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int),
         ("in_act", C.c_int), ("in_slope", C.c_float),
+        ("ln_s", C.c_void_p), ("ln_sa", C.c_void_p), ("ln_ca", C.c_void_p), ("ln_eps", C.c_float),
         ("lora_a", C.c_void_p), ("lora_b", C.c_void_p),
         ("Rp", C.c_int),
         ("lora_t_out", C.c_void_p),

@@ -41,6 +41,8 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
+  ALDM_CHECK_ARG(!p->ln_s || (p->KH == 1 && p->KW == 1 && p->Cin2 == 0 && p->splits <= 1 && (p->Rp == 0 || (p->ln_sa && p->ln_ca))),
+                 "igemm: folded LayerNorm needs a 1x1 single-source GEMM without split-K (and ln_sa/ln_ca with LoRA)");
   ALDM_CHECK_ARG(p->ring == 0 || (p->ring >= 2 && p->ring <= 4), "igemm: ring must be 0 (auto) or 2..4");
   ALDM_CHECK_ARG(p->in_dilate == 0 || (p->in_dilate == 2 && p->UH == 0), "igemm: in_dilate must be 0 or 2 (and excludes UH/UW)");
 
@@ -75,6 +77,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.w_bytes = (unsigned)wb;
     d.la_bytes = (unsigned)lb;
     d.lb_bytes = (unsigned)(2ull * p->Cout * p->Rp);
+    d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
 #ifdef ALDM_DIAG
     d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer
 #else

@@ -43,6 +43,7 @@ struct IgemmDev {
   int tiles_n;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
   unsigned long long* diag;   // diagnostic builds only
+  const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;   // LayerNorm folded into the GEMM (see below)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -198,7 +199,8 @@ struct EpiCfg {
 
 template <int BM, int BN, int MI, int NI, bool VT>
 __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], char* smem, bool vt_wg, int m0,
-                                               int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid) {
+                                               int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid,
+                                               const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
   float* Cs = reinterpret_cast<float*>(smem);
   __syncthreads();                                           // every wave is done with the K-loop images
@@ -230,14 +232,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       if (m + 7 < p.M && pix + 7 < p.OHW && ((p.vt_ld & 7) == 0) && ((pix & 7) == 0) && ((p.vt_bs & 7) == 0)) {
         bf16x8 t;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = (bf16)(src[q] + bb);
+        for (int q = 0; q < 8; ++q) {
+          float val = src[q];
+          if (lnst) val = lnst[BM + cm + q] * (val - lnst[cm + q] * p.ln_s[n]);
+          t[q] = (bf16)(val + bb);
+        }
         *reinterpret_cast<bf16x8*>(o) = t;
       } else {
         for (int q = 0; q < 8; ++q) {
           const int mq = m + q;
           if (mq >= p.M) break;
           const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
-          p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(src[q] + bb);
+          float val = src[q];
+          if (lnst) val = lnst[BM + cm + q] * (val - lnst[cm + q] * p.ln_s[n]);
+          p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(val + bb);
         }
       }
     }
@@ -271,6 +279,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float val = src[q], gate = src[16 + q];
+        if (lnst) {
+          val = lnst[BM + r] * (val - lnst[r] * p.ln_s[nv + q]);
+          gate = lnst[BM + r] * (gate - lnst[r] * p.ln_s[nv + 16 + q]);
+        }
         if (p.bias) { val += p.bias[nv + q]; gate += p.bias[nv + 16 + q]; }
         v[q] = val * gelu_erf_f(gate);
       }
@@ -286,6 +298,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = src[q];
+    if (lnst) {
+      const float mu = lnst[r], rs = lnst[BM + r];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (n + q < p.N) v[q] = rs * (v[q] - mu * p.ln_s[n + q]);
+    }
     if (p.bias) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) if (n + q < p.N) v[q] += p.bias[n + q];
@@ -553,6 +570,8 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   constexpr int RT_W = RP / 16 / WN;
   constexpr unsigned OOB = 0x80000000u;
   static_assert((D - 1) * L < 64, "vmcnt immediate");
+  constexpr int LDS_LOOP = S * STAGE + (RP > 0 ? BN * 128 : 0);
+  constexpr int LDS_MAIN = LDS_LOOP > EpiCfg<BM, BN>::BYTES ? LDS_LOOP : EpiCfg<BM, BN>::BYTES;   // stats live past it
 
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [S][ A: BM x 128 B | B: BROWS x 128 B ]
 
@@ -742,6 +761,23 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   unsigned long long dg_wait = 0, dg_bar = 0, dg_issue = 0, dg_mma = 0;
 #define ALDM_STAMP(var) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; }
 #endif
+  // LayerNorm folded into the GEMM (p.ln_s != nullptr): y = rstd_m (x_m . W'_n - mean_m s_n) + c_n with W' = W diag(gamma),
+  // s_n = sum_k W'_nk, c_n = beta . W_n (+ bias).  The row statistics come from the SAME activation tiles the MFMAs consume:
+  // TPR threads per row sum their share of every landed K-tile out of LDS -- no separate LayerNorm launch, no normalised
+  // tensor in HBM.
+  constexpr int TPR = THREADS / BM;                       // threads per tile row
+  constexpr int CPT = 8 / TPR;                            // 16-byte chunks of a 64-wide K-tile per thread
+  const bool lnf = p.ln_s != nullptr;
+  const int ln_row = tid / TPR, ln_c0 = (tid % TPR) * CPT;
+  float ln_sum = 0.f, ln_sq = 0.f;
+  auto ln_accum = [&](const char* As) {
+#pragma unroll
+    for (int cc = 0; cc < CPT; ++cc) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(As + ln_row * 128 + swz(ln_row, ln_c0 + cc) * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ln_sum += f; ln_sq += f * f; }
+    }
+  };
   auto main_loop = [&](auto vtf) {
     int st = 0, st_fill = D;
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -761,6 +797,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
 #ifdef ALDM_DIAG
       ALDM_STAMP(t3)
 #endif
+      if (lnf) ln_accum(smem + st * STAGE);
       mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 0, true);
       mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 1, true);
 #ifdef ALDM_DIAG
@@ -781,6 +818,18 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
 #endif
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
+  float* const lnst = lnf ? reinterpret_cast<float*>(smem + LDS_MAIN) : nullptr;   // [2][BM]: mean, rstd (past every other image)
+  if (lnf) {
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) { ln_sum += __shfl_xor(ln_sum, o, 64); ln_sq += __shfl_xor(ln_sq, o, 64); }
+    if ((tid % TPR) == 0) {
+      const float invk = 1.f / (float)(p.Ctot * p.KH * p.KW);
+      const float mu = ln_sum * invk;
+      lnst[ln_row] = mu;
+      lnst[BM + ln_row] = rsqrtf(fmaxf(ln_sq * invk - mu * mu, 0.f) + p.ln_eps);
+    }
+    __syncthreads();
+  }
 
   // ---- LoRA: T (bf16) -> LDS stage 0, then one more K-step against the pre-scaled B ----
   if (RP > 0) {
@@ -791,6 +840,11 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
       for (int t = 0; t < RT_W; ++t) {
         const int r = wm * (BM / WM) + i * 16 + lrow;
         const int col = (wn * RT_W + t) * 16 + lq * 4;
+        if (lnf) {   // T'' = t - mean sA + cA / rstd : the epilogue's rstd (acc - mean s) + c then also fixes the LoRA term
+          const float mu = lnst[r], irs = 1.f / lnst[BM + r];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tacc[i][t][e] = tacc[i][t][e] - mu * p.ln_sa[col + e] + p.ln_ca[col + e] * irs;
+        }
         bf16x4 tv = {(bf16)tacc[i][t][0], (bf16)tacc[i][t][1], (bf16)tacc[i][t][2], (bf16)tacc[i][t][3]};
         *reinterpret_cast<bf16x4*>(As + r * 128 + swz(r, col >> 3) * 16 + (col & 7) * 2) = tv;
         if (p.lora_t_out && tile_n == 0 && m0 + r < p.M)
@@ -803,7 +857,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
       else mma_step(std::false_type{}, smem, LBs, ks, false);
     }
   }
-  igemm_epilogue<BM, BN, MI, NI, VT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid);
+  igemm_epilogue<BM, BN, MI, NI, VT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
 #endif
 }
 
@@ -848,7 +902,7 @@ template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
 int launch_cfg(const IgemmDev& d, hipStream_t st) {
   // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
   constexpr size_t lds_loop = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
-  constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
+  constexpr size_t lds = (lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES) + 2 * BM * sizeof(float);
   static bool attr_done = false;   // one-time, idempotent; races are benign
   void (*kern)(const IgemmDev);
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
@@ -890,6 +944,10 @@ int launch_tile(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   // activation and < 2 GiB activations (32-bit buffer offsets, 0x80000000 = "padded tap").
   const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u &&
                     d.x2_bytes < 0x80000000u;
+  if (!fast && d.ln_s) {
+    aldm_set_error("igemm: the folded LayerNorm needs the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
+    return ALDM_E_UNSUPPORTED;
+  }
   if (!fast) return launch_rp<BM, BN, WM, WN, 0>(d, Rp, vt, st);
   const int S = ring ? ring : (Rp ? SL : S0);
   if (S == 2) return launch_rp<BM, BN, WM, WN, 2>(d, Rp, vt, st);

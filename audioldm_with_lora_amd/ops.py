@@ -42,6 +42,10 @@ class PackedW:
     lora_a: Optional[torch.Tensor] = None      # [Rp][Kpad] bf16
     lora_b: Optional[torch.Tensor] = None      # [N][Rp] bf16, pre-scaled by alpha/r
     Rp: int = 0
+    ln_s: Optional[torch.Tensor] = None        # LayerNorm folded into the GEMM: fp32 [N] column sums of W diag(gamma)
+    ln_sa: Optional[torch.Tensor] = None       # fp32 [Rp]: row sums of A diag(gamma)
+    ln_ca: Optional[torch.Tensor] = None       # fp32 [Rp]: A beta
+    ln_eps: float = 1e-5
 
     @property
     def Kpad(self):
@@ -86,6 +90,26 @@ def pack_geglu(weight: torch.Tensor, bias: torch.Tensor) -> PackedW:
     return pw
 
 
+def pack_linear_ln(weight, bias, gamma, beta, eps=1e-5, geglu=False):
+    """Linear applied to LayerNorm(x) with the norm folded in:  LN(x) W^T + b = rstd (x W'^T - mean s) + c,
+    W' = W diag(gamma) (bf16), s = row sums of the bf16 W' (what the MFMA really sums), c = W beta + b."""
+    w = weight.detach().float()
+    g, bt = gamma.detach().float(), beta.detach().float()
+    wp = (w * g[None, :]).to(torch.bfloat16)
+    s = wp.float().sum(1)
+    c = w @ bt + (bias.detach().float() if bias is not None else 0.0)
+    if geglu:
+        inner = w.shape[0] // 2
+        idx = torch.arange(inner, device=w.device).view(-1, 16)
+        order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+        wp, s, c = wp[order], s[order], c[order]
+    pw = PackedW(_pad_k(wp), c.contiguous(), w.shape[0], w.shape[1])
+    pw.geglu = geglu
+    pw.ln_s, pw.ln_eps = s.contiguous(), eps
+    pw._ln = (g, bt)
+    return pw
+
+
 def attach_lora(pw: PackedW, parts):
     """parts: list of (row_offset, n_rows, A [r, K], B [n_rows, r], scaling) -- one per LoRA-wrapped target
     that shares this GEMM.  Builds A_cat [Rp][Kpad] and the block-structured, pre-scaled B_ext [N][Rp]."""
@@ -101,13 +125,25 @@ def attach_lora(pw: PackedW, parts):
     dev = pw.w.device
     a = torch.zeros(rp, pw.Kpad, dtype=torch.bfloat16, device=dev)
     b = torch.zeros(pw.N, rp, dtype=torch.bfloat16, device=dev)
+    ln = getattr(pw, "_ln", None) if pw.ln_s is not None else None
+    sa = torch.zeros(rp, dtype=torch.float32, device=dev)
+    ca = torch.zeros(rp, dtype=torch.float32, device=dev)
     col = 0
     for row0, nrows, A, Bm, s in parts:
         r, k = A.shape
-        a[col:col + r, :k] = A.detach().to(torch.bfloat16)
+        Af = A.detach().float()
+        if ln is not None:                      # LayerNorm folded: A' = A diag(gamma), sA = row sums, cA = A beta
+            Ap = (Af * ln[0][None, :]).to(torch.bfloat16)
+            sa[col:col + r] = Ap.float().sum(1)
+            ca[col:col + r] = Af @ ln[1]
+        else:
+            Ap = Af.to(torch.bfloat16)
+        a[col:col + r, :k] = Ap
         b[row0:row0 + nrows, col:col + r] = (Bm.detach().float() * s).to(torch.bfloat16)
         col += r
     pw.lora_a, pw.lora_b, pw.Rp = a.contiguous(), b.contiguous(), rp
+    if ln is not None:
+        pw.ln_sa, pw.ln_ca = sa, ca
     return pw
 
 
@@ -207,6 +243,10 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         a.lora_a, a.lora_b, a.Rp = pw.lora_a.data_ptr(), pw.lora_b.data_ptr(), pw.Rp
         a.lora_t_out = lora_t_out.data_ptr() if lora_t_out is not None else None
     a.bias = pw.bias.data_ptr() if pw.bias is not None else None
+    if pw.ln_s is not None:
+        a.ln_s, a.ln_eps = pw.ln_s.data_ptr(), pw.ln_eps
+        if pw.Rp:
+            a.ln_sa, a.ln_ca = pw.ln_sa.data_ptr(), pw.ln_ca.data_ptr()
     if rowbias is not None:
         assert rowbias.dtype == torch.float32
         a.rowbias, a.rowbias_ld = rowbias.data_ptr(), rowbias_ld
@@ -225,7 +265,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     M = B * OH * OW
     ktiles = pw.Kpad // BK
     if splits is None:
-        splits = 1 if (vt is not None or pw.N % 4) else auto_splits(M, pw.N, ktiles)
+        splits = 1 if (vt is not None or pw.N % 4 or pw.ln_s is not None) else auto_splits(M, pw.N, ktiles)
     a.splits = splits
     if splits > 1:
         ws = _workspace(splits * M * pw.N * 4, x.device)

@@ -298,8 +298,11 @@ class LoraTrainer:
         if qkv_site is not None:
             qkv = t_lora_linear(tape, hn, qkv_site)
         else:
-            pw = Pa.qkv
-            qkv = t_conv(tape, t_view(tape, hn, (1, 1, B * N, C)), ops.PackedW(pw.w, pw.bias, pw.N, pw.Cin))
+            if "qkv_plain" not in Pa.__dict__:
+                wq, wk, wv = _base(tblk_attn.to_q), _base(tblk_attn.to_k), _base(tblk_attn.to_v)
+                bias = torch.cat([wq.bias, wk.bias, wv.bias]) if wq.bias is not None else None
+                Pa.qkv_plain = ops.pack_linear(torch.cat([wq.weight, wk.weight, wv.weight]), bias)
+            qkv = t_conv(tape, t_view(tape, hn, (1, 1, B * N, C)), Pa.qkv_plain)
             qkv = t_view(tape, qkv, (B * N, 3 * C))
         qkvT = ops.transpose_tokens(qkv.t, B, N, 3 * C)
         o_t, lse = ops.attention_train(qkv.t, qkvT, B, N, H, d)
@@ -325,7 +328,10 @@ class LoraTrainer:
         h = self._attention(tape, tb.attn1, Pt.attn1, t_layernorm(tape, h, *Pt.ln[0]), h, B, N)
         h = self._attention(tape, tb.attn2, Pt.attn2, t_layernorm(tape, h, *Pt.ln[1]), h, B, N)
         n3 = t_layernorm(tape, h, *Pt.ln[2])
-        ff1 = Pt.__dict__.setdefault("ff1_plain", ops.PackedW(Pt.ff1.w, Pt.ff1.bias, Pt.ff1.N, Pt.ff1.Cin))   # un-fused GEGLU
+        if "ff1_plain" not in Pt.__dict__:                    # un-fused GEGLU, LayerNorm NOT folded (the backward needs LN(h))
+            gp = ops.pack_geglu(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
+            Pt.ff1_plain = ops.PackedW(gp.w, gp.bias, gp.N, gp.Cin)
+        ff1 = Pt.ff1_plain
         hp = t_view(tape, t_conv(tape, t_view(tape, n3, (1, 1, B * N, C)), ff1), (B * N, 8 * C))
         g = Var(ops.geglu_fwd(hp.t), hp.rg)
         if hp.rg:

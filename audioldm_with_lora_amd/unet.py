@@ -169,7 +169,9 @@ def pack_resnet(r: ResnetBlock2D):
         groups=r.groups, eps=r.eps, cout=r.cout, temb_off=0)
 
 
-def pack_attention(a: Attention):
+def pack_attention(a: Attention, ln=None):
+    """ln = (gamma, beta) of the LayerNorm feeding this attention: folded into the fused QKV GEMM when the LDS-DMA
+    path can take it (C % 64 == 0); the caller then passes the RAW hidden state."""
     wq, bq, lq = _lin(a.to_q)
     wk, bk, lk = _lin(a.to_k)
     wv, bv, lv = _lin(a.to_v)
@@ -178,11 +180,12 @@ def pack_attention(a: Attention):
     bias = None
     if bq is not None:
         bias = torch.cat([bq, bk, bv])
-    qkv = ops.pack_linear(torch.cat([wq, wk, wv]), bias)
+    fold = ln is not None and c % 64 == 0
+    qkv = ops.pack_linear_ln(torch.cat([wq, wk, wv]), bias, ln[0], ln[1]) if fold else ops.pack_linear(torch.cat([wq, wk, wv]), bias)
     ops.attach_lora(qkv, [None if l is None else (i * c, c, l[0], l[1], l[2]) for i, l in enumerate((lq, lk, lv))])
     out = ops.pack_linear(wo, bo)
     ops.attach_lora(out, [None if lo is None else (0, wo.shape[0], lo[0], lo[1], lo[2])])
-    return SimpleNamespace(qkv=qkv, out=out, heads=a.heads, d=a.dim_head, c=c)
+    return SimpleNamespace(qkv=qkv, out=out, heads=a.heads, d=a.dim_head, c=c, ln_folded=fold)
 
 
 def pack_transformer(t: Transformer2DModel):
@@ -191,8 +194,10 @@ def pack_transformer(t: Transformer2DModel):
         gn_g=_f32(t.norm.weight), gn_b=_f32(t.norm.bias), groups=t.groups,
         proj_in=ops.pack_conv(t.proj_in.weight, t.proj_in.bias), proj_out=ops.pack_conv(t.proj_out.weight, t.proj_out.bias),
         ln=[(_f32(n.weight), _f32(n.bias)) for n in (blk.norm1, blk.norm2, blk.norm3)],
-        attn1=pack_attention(blk.attn1), attn2=pack_attention(blk.attn2),
-        ff1=ops.pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias),
+        attn1=pack_attention(blk.attn1, (blk.norm1.weight, blk.norm1.bias)),
+        attn2=pack_attention(blk.attn2, (blk.norm2.weight, blk.norm2.bias)),
+        ff1=(ops.pack_linear_ln(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, blk.norm3.weight, blk.norm3.bias, geglu=True)
+             if t.channels % 64 == 0 else ops.pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias)),
         ff2=ops.pack_linear(blk.ff.net[2].weight, blk.ff.net[2].bias))
 
 
@@ -227,9 +232,10 @@ def run_transformer(P, x):
     N = H * W
     h = ops.groupnorm(x, P.gn_g, P.gn_b, P.groups, 1e-6, ACT_NONE)
     h = ops.conv(h, P.proj_in).view(B * N, C)
-    h = run_attention(P.attn1, ops.layernorm(h, *P.ln[0]), h, B, N)
-    h = run_attention(P.attn2, ops.layernorm(h, *P.ln[1]), h, B, N)     # encoder_hidden_states=None: self-attention
-    g = ops.linear(ops.layernorm(h, *P.ln[2]), P.ff1)
+    # LayerNorms are folded into the consuming GEMM where possible (row statistics computed in-kernel)
+    h = run_attention(P.attn1, h if P.attn1.ln_folded else ops.layernorm(h, *P.ln[0]), h, B, N)
+    h = run_attention(P.attn2, h if P.attn2.ln_folded else ops.layernorm(h, *P.ln[1]), h, B, N)   # encoder_hidden_states=None: self-attention
+    g = ops.linear(h if P.ff1.ln_s is not None else ops.layernorm(h, *P.ln[2]), P.ff1)
     h = ops.linear(g, P.ff2, res=h)
     return ops.conv(h.view(B, H, W, C), P.proj_out, res=x)
 

@@ -60,6 +60,11 @@ typedef struct {
   int KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;   /* dil may be negative */
   int OH, OW, Cout;
   int in_act;  float in_slope;      /* activation applied to X while it is gathered (vocoder leaky-relu) */
+  /* LayerNorm folded into the GEMM (BasicTransformerBlock.norm1/2/3 feeding to_q/k/v and the GEGLU projection):
+       y = rstd_m (x_m . W'_n - mean_m ln_s[n]) + bias[n]     W' = W diag(gamma),  ln_s[n] = sum_k W'[n][k],
+       bias[n] = beta . W[n] (+ linear bias) folded by the host; row statistics are computed in-kernel from the raw x tiles.
+     With LoRA: ln_sa[j] = sum_k (A diag(gamma))[j][k], ln_ca[j] = beta . A[j].  null = plain GEMM. */
+  const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;
   /* LoRA side channel (linear layers): T = X A^T, acc += T B'^T with B' = (alpha/r) B */
   const void* lora_a;       /* [Rp][Kpad] bf16 */
   const void* lora_b;       /* [Cout][Rp] bf16, pre-scaled */

@@ -226,3 +226,25 @@ def test_elementwise(ops):
     assert torch.equal(y.float().cpu(), bf(x).permute(0, 2, 3, 1))
     z = ops.nhwc_to_nchw_f32(y)
     assert torch.equal(z.cpu(), bf(x))
+
+
+@pytest.mark.parametrize("M,Cc,N,r,geglu", [(1000, 256, 768, 4, False), (300, 128, 1024, 0, True), (70, 640, 1920, 16, False)])
+def test_layernorm_folded_into_gemm(ops, M, Cc, N, r, geglu):
+    """LN(x) W^T (+ LoRA on LN(x)) computed from the RAW x with in-kernel row statistics."""
+    g = torch.Generator().manual_seed(21)
+    x = bf(torch.randn(M, Cc, generator=g) * 1.7 + 0.4)
+    w = bf(torch.randn(N, Cc, generator=g) / math.sqrt(Cc))
+    b = torch.randn(N, generator=g)
+    gm, bt = torch.randn(Cc, generator=g) * 0.3 + 1, torch.randn(Cc, generator=g) * 0.2
+    xn = F.layer_norm(x, (Cc,), gm, bt, 1e-5)
+    want = xn @ w.t() + b
+    pw = ops.pack_linear_ln(w.to(DEV), b.to(DEV), gm.to(DEV), bt.to(DEV), geglu=geglu)
+    if r:
+        A = bf(torch.randn(r, Cc, generator=g) / r)
+        Bm = bf(torch.randn(N, r, generator=g) * 0.05)
+        want = want + 2.0 * (xn @ A.t()) @ Bm.t()
+        ops.attach_lora(pw, [(0, N, A.to(DEV), Bm.to(DEV), 2.0)])
+    if geglu:
+        want = want[:, :N // 2] * F.gelu(want[:, N // 2:])
+    got = ops.linear(x.to(torch.bfloat16).to(DEV), pw)
+    close(got, want, rtol=2e-2)
