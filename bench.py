@@ -70,6 +70,29 @@ def kernel_profile(engine, fine=False):
     return agg
 
 
+def traffic_from_profile(label):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC summary (tools/pmc_traffic.py over two
+    rocprofv3 --pmc passes of this same command; MI355X_MICROARCH.md correction applied).  None when no summary exists."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    m = re.match(r"igemm_(\d+)x(\d+)_r(\d+)(_vt)?", label)
+    if not files or not m:
+        return None, None
+    prof = json.load(open(files[-1]))
+    bm, bn, rp, vt = m.group(1), m.group(2), m.group(3), "true" if m.group(4) else "false"
+    tot = n = 0
+    for k, v in prof.items():
+        km = re.match(r"igemm_pipe_kernel<(\d+), (\d+), 2, 2, (\d+), (\w+), (\d+)>", k)
+        if km and (km.group(1), km.group(2), km.group(3), km.group(4)) == (bm, bn, rp, vt):
+            # the split-K label is separate in the live profile; ring depth 3 is what the split-K launches use
+            if ("_sk" in label) != (km.group(5) == "3" and bm == "64"):
+                continue
+            tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
+            n += v["launches_sampled"]
+    return (tot / n if n else None), os.path.basename(files[-1])
+
+
 def cpu_baseline(batch, height, width, rank_lora, max_seconds=30.0):
     """The CPU oracle (kind "port": our restatement of the diffusers/peft path) timed on this box's host cores."""
     from oracle import lora as olora
@@ -230,8 +253,12 @@ def main():
                       f"{v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:8.1f} GB/s", file=sys.stderr)
             print(f"eager sum {total_ms:.3f} ms over {sum(v['launches'] for v in prof.values())} launches", file=sys.stderr)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = traffic_from_profile(dom_label)
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": (round(traffic) if traffic else None),
+                    "traffic_unit": "HBM bytes/launch (PMC, profiles/%s)" % traffic_src if traffic else None,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
+                    "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
                     "kernel": dom_label, "launches_per_step": dom["launches"],
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "share_of_step": round(dom["ms"] / total_ms, 3)}
