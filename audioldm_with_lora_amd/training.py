@@ -243,7 +243,7 @@ class LoraTrainer:
     """One process per GPU; `world`/`rank` follow torch.distributed when it is initialised (RCCL over xGMI)."""
 
     def __init__(self, unet: UNet2DConditionModel, scheduler, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-5, eps=1e-8,
-                 max_train_steps=97000, lr_end=1e-7, power=1.0, device="cuda"):
+                 max_train_steps=97000, lr_end=1e-7, power=1.0, device="cuda", use_graph=True):
         self.unet, self.scheduler = unet, scheduler
         self.dev = torch.device(device)
         self.lr0, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
@@ -252,6 +252,8 @@ class LoraTrainer:
         self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.flat = FlatLora(unet, self.dev)
+        self.use_graph, self.graph, self._static, self._eager_steps = use_graph, None, None, 0
+        self.ac_dev = scheduler.alphas_cumprod.to(self.dev, torch.float32)
         self._build_sites()
         dp.broadcast_(self.flat.params, src=0)                  # DDP's initial parameter broadcast (C3), LoRA buffer only
 
@@ -397,21 +399,51 @@ class LoraTrainer:
             return self.lr_end
         return (self.lr0 - self.lr_end) * (1 - step / self.max_train_steps) ** self.power + self.lr_end
 
-    def loss_and_grads(self, latents, noise, timesteps, prompt_embeds):
-        """Fills the flat gradient buffer (sum over this rank's batch-mean loss); returns the device loss scalar view."""
+    def _fwd_bwd(self, latents, noise, timesteps, prompt_embeds):
+        """Device-only launch sequence (capturable): repack LoRA -> add_noise -> forward tape -> MSE -> backward."""
         f = self.flat
         self.repack()
         f.grads.zero_()
-        noisy = self.scheduler.add_noise(latents.to(self.dev, torch.float32), noise.to(self.dev, torch.float32),
-                                         timesteps.to(self.dev))
+        ac = self.ac_dev[timesteps]
+        coef = torch.stack([ac ** 0.5, (1 - ac) ** 0.5], dim=1).contiguous()
+        noisy = ops.add_noise(latents, noise, coef)
         x_in = ops.nchw_to_nhwc(noisy)
-        tgt = ops.nchw_to_nhwc(noise.to(self.dev, torch.float32).contiguous(), out_f32=True)
-        t_dev = timesteps.to(self.dev, torch.float32).contiguous()
-        cls = ops.f32_to_bf16(prompt_embeds.to(self.dev, torch.float32).contiguous())
+        tgt = ops.nchw_to_nhwc(noise, out_f32=True)
+        t_dev = timesteps.to(torch.float32)
+        cls = ops.f32_to_bf16(prompt_embeds)
         tape = Tape()
         pred = self.forward(tape, x_in, t_dev, cls)
         pred.g = ops.mse_grad(pred.t, tgt, f.grads[f.n:])
         tape.backward()
+
+    def _to_dev(self, latents, noise, timesteps, prompt_embeds):
+        return (latents.to(self.dev, torch.float32).contiguous(), noise.to(self.dev, torch.float32).contiguous(),
+                timesteps.to(self.dev, torch.int64).contiguous(), prompt_embeds.to(self.dev, torch.float32).contiguous())
+
+    def loss_and_grads(self, latents, noise, timesteps, prompt_embeds):
+        """Fills the flat gradient buffer (this rank's batch-mean loss in the last slot); returns that loss slot.
+        After two eager warm-up steps the whole launch sequence (~1000 kernels) is captured once into a hipGraph and
+        replayed from static input buffers -- the eager step is host-launch-bound."""
+        f = self.flat
+        args = self._to_dev(latents, noise, timesteps, prompt_embeds)
+        if not self.use_graph:
+            self._fwd_bwd(*args)
+            return f.grads[f.n:]
+        if self.graph is not None and all(a.shape == b.shape for a, b in zip(args, self._static)):
+            for dst, src in zip(self._static, args):
+                dst.copy_(src)
+            self.graph.replay()
+            return f.grads[f.n:]
+        self._eager_steps += 1
+        if self._eager_steps <= 2:
+            self._fwd_bwd(*args)
+            return f.grads[f.n:]
+        self._static = tuple(a.clone() for a in args)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._fwd_bwd(*self._static)
+        self.graph.replay()
         return f.grads[f.n:]
 
     def step(self, latents, noise, timesteps, prompt_embeds):
