@@ -560,6 +560,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
 __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef ALDM_DIAG
+  unsigned long long dg_t_entry; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_entry) :: "memory");
+#endif
   static_assert(WM * WN == 4, "4 waves");
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr int BROWS = BN + RP;
@@ -811,10 +814,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   };
   if (VT && vt_wg) main_loop(std::true_type{}); else main_loop(std::false_type{});
 #ifdef ALDM_DIAG
-  if (p.diag && lane == 0) {
-    unsigned long long* o = p.diag + ((long long)(blockIdx.x + gridDim.x * blockIdx.z) * 4 + wave) * 4;
-    o[0] = dg_wait; o[1] = dg_bar; o[2] = dg_issue; o[3] = dg_mma;
-  }
+  unsigned long long dg_t_loop_end; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_loop_end) :: "memory");
 #endif
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -858,6 +858,16 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
     }
   }
   igemm_epilogue<BM, BN, MI, NI, VT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
+#ifdef ALDM_DIAG
+  if (p.diag && lane == 0) {
+    unsigned long long dg_t_end; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_end) :: "memory");
+    unsigned long long* o = p.diag + ((long long)(blockIdx.x + gridDim.x * blockIdx.z) * 4 + wave) * 8;
+    o[0] = dg_wait; o[1] = dg_bar; o[2] = dg_issue; o[3] = dg_mma;
+    o[4] = dg_t_loop_end - dg_t_entry - (dg_wait + dg_bar + dg_issue + dg_mma);   // prologue (everything before / around the loop)
+    o[5] = dg_t_end - dg_t_loop_end;                                               // LoRA tail + epilogue incl. store drain
+    o[6] = dg_t_entry; o[7] = dg_t_end;
+  }
+#endif
 #endif
 }
 

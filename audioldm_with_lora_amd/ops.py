@@ -273,7 +273,13 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if tile == 0:
         tile = _lib.TILE_64x64 if pw.Rp else pick_tile(M, pw.N)      # LoRA GEMMs are short-K: favour many workgroups
     a.tile = tile
-    a.ring = ring if ring else (2 if ktiles <= 24 else 3)     # sweep: short K loops want occupancy, deep ones a deeper ring
+    if not ring:
+        bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128)}[tile]
+        nwg = math.ceil(M / bm) * math.ceil(pw.N / bn) * max(1, splits)
+        # few workgroups (low-resolution levels): nothing else hides the HBM latency of the weight stream -> deepest ring;
+        # many workgroups: occupancy matters more than depth (tools/bench_igemm.py sweeps)
+        ring = 4 if nwg <= 512 else (2 if ktiles <= 24 else 3)
+    a.ring = ring
     ktot = KH * KW * pw.Cin
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)
     nbytes = 2.0 * (B * IH * IW * pw.Cin + pw.N * ktot + M * ncols)
