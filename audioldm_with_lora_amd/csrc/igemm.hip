@@ -77,6 +77,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.w_bytes = (unsigned)wb;
     d.la_bytes = (unsigned)lb;
     d.lb_bytes = (unsigned)(2ull * p->Cout * p->Rp);
+    d.fd_ohw = make_fastdiv((unsigned)d.OHW); d.fd_ow = make_fastdiv((unsigned)d.OW);
     d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
 #ifdef ALDM_DIAG
     d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer

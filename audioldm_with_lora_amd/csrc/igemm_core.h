@@ -26,6 +26,21 @@ namespace aldm_igemm_detail {
 constexpr int BK = 64;
 constexpr int THREADS = 256;
 
+// n / d for a runtime-constant d: q = (umulhi(n, mul) + n) >> shift  (round-up magic; exact for 0 <= n < 2^31).
+// A hardware integer division is ~50 instructions; the kernels divide by OH*OW and OW in their prologue AND epilogue.
+struct FastDiv { unsigned mul, shift; };
+__device__ __forceinline__ int fdiv(int n, FastDiv d) {
+  return (int)(((unsigned long long)__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
+}
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+  return f;
+}
+
 struct IgemmDev {
   const bf16* x; const bf16* x2; const bf16* w; const bf16* lora_a; const bf16* lora_b;
   bf16* lora_t_out;
@@ -43,6 +58,7 @@ struct IgemmDev {
   int tiles_n;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
   unsigned long long* diag;   // diagnostic builds only
+  FastDiv fd_ohw, fd_ow;
   const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;   // LayerNorm folded into the GEMM (see below)
 };
 
@@ -127,7 +143,7 @@ __device__ __forceinline__ void add_bias4(const IgemmDev& p, int m, int n, float
 // the K loop itself), and global stores become full 16-byte row segments.
 __device__ __forceinline__ void epi8(const IgemmDev& p, int m, int n, int ncols, float* v) {
   // v[0..7]: output columns n..n+7 of output row m, bias already added
-  const int b = m / p.OHW;
+  const int b = fdiv(m, p.fd_ohw);
   const int pix = m - b * p.OHW;
   const long long row = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
   const bool vec = (n + 7 < ncols) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
@@ -227,7 +243,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       if (n >= p.N || m >= p.M) continue;
       const float bb = p.bias ? p.bias[n] : 0.f;
       const float* src = Cs + rn * E::LDT + cm;
-      const int b = m / p.OHW, pix = m - b * p.OHW;
+      const int b = fdiv(m, p.fd_ohw), pix = m - b * p.OHW;
       bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
       if (m + 7 < p.M && pix + 7 < p.OHW && ((p.vt_ld & 7) == 0) && ((pix & 7) == 0) && ((p.vt_bs & 7) == 0)) {
         bf16x8 t;
@@ -242,7 +258,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         for (int q = 0; q < 8; ++q) {
           const int mq = m + q;
           if (mq >= p.M) break;
-          const int bq = mq / p.OHW, pq = mq - bq * p.OHW;
+          const int bq = fdiv(mq, p.fd_ohw), pq = mq - bq * p.OHW;
           float val = src[q];
           if (lnst) val = lnst[BM + cm + q] * (val - lnst[cm + q] * p.ln_s[n]);
           p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(val + bb);
@@ -308,7 +324,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       for (int q = 0; q < 8; ++q) if (n + q < p.N) v[q] += p.bias[n + q];
     }
     if (p.rowbias) {
-      const float* rb = p.rowbias + (long long)(m / p.OHW) * p.rowbias_ld;
+      const float* rb = p.rowbias + (long long)fdiv(m, p.fd_ohw) * p.rowbias_ld;
 #pragma unroll
       for (int q = 0; q < 8; ++q) if (n + q < p.N) v[q] += rb[n + q];
     }
@@ -348,9 +364,9 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
     const int m = m0 + rbase + 32 * ps;
     a_ok[ps] = m < p.M;
     const int mm = a_ok[ps] ? m : 0;
-    const int b = mm / p.OHW;
+    const int b = fdiv(mm, p.fd_ohw);
     const int pix = mm - b * p.OHW;
-    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    const int oh = fdiv(pix, p.fd_ow), ow = pix - oh * p.OW;
     a_b[ps] = b;
     a_ih0[ps] = oh * p.sh - p.ph;
     a_iw0[ps] = ow * p.sw - p.pw;
@@ -609,9 +625,9 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
 #pragma unroll
   for (int ps = 0; ps < A_PASSES; ++ps) {
     const int m = min(m0 + rbase + 32 * ps, p.M - 1);
-    const int b = m / p.OHW;
+    const int b = fdiv(m, p.fd_ohw);
     const int pix = m - b * p.OHW;
-    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    const int oh = fdiv(pix, p.fd_ow), ow = pix - oh * p.OW;
     a_pix0[ps] = b * p.IH * p.IW;
     a_ih0[ps] = oh * p.sh - p.ph;
     a_iw0[ps] = ow * p.sw - p.pw;
@@ -959,7 +975,10 @@ int launch_tile(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
     return ALDM_E_UNSUPPORTED;
   }
   if (!fast) return launch_rp<BM, BN, WM, WN, 0>(d, Rp, vt, st);
-  const int S = ring ? ring : (Rp ? SL : S0);
+  int S = ring ? ring : (Rp ? SL : S0);
+  // never ask for more than the 160 KiB of LDS a workgroup can own (ring + LoRA-B image + row statistics)
+  auto lds_need = [&](int s) { return (size_t)s * (BM + BN + Rp) * 128 + (Rp ? (size_t)BN * 128 : 0) + 2 * BM * sizeof(float); };
+  while (S > 2 && lds_need(S) > 160 * 1024) --S;
   if (S == 2) return launch_rp<BM, BN, WM, WN, 2>(d, Rp, vt, st);
   if (S == 3) return launch_rp<BM, BN, WM, WN, 3>(d, Rp, vt, st);
   return launch_rp<BM, BN, WM, WN, 4>(d, Rp, vt, st);
