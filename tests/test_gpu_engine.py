@@ -68,3 +68,23 @@ def test_scheduler_step_and_add_noise_match_oracle():
     t = torch.tensor([0, 999])
     got = s.add_noise(x.cuda(), e.cuda(), t.cuda()).cpu()
     torch.testing.assert_close(got, o.add_noise(x, e, t), rtol=1e-6, atol=1e-6)
+
+
+def test_guidance_one_equals_unconditional_path_and_linearity_of_step():
+    """Properties of the fused CFG + DDIM kernel: g = 1 reduces to the text branch; the update matches the closed form."""
+    from audioldm_with_lora_amd import ops
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    s = DDIMScheduler()
+    s.set_timesteps(200)
+    coef = s.coefficient_table().cuda()
+    idx = torch.tensor([17], dtype=torch.int32, device="cuda")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 50, 16, 8, generator=g).cuda()
+    e = torch.randn(4, 50, 16, 8, generator=g).cuda()
+    xa, xb = x.clone(), x.clone()
+    ops.cfg_ddim_step(e, xa, True, 1.0, coef, idx, None)              # g = 1: eps = eps_text
+    ops.cfg_ddim_step(e[2:].contiguous(), xb, False, 0.0, coef, idx, None)
+    torch.testing.assert_close(xa, xb, rtol=1e-5, atol=1e-5)      # eps_u + 1*(eps_t - eps_u) == eps_t up to fp32 rounding
+    c = coef[17].cpu()
+    want = c[2] * ((x.cpu() - c[1] * e[2:].cpu()) / c[0]) + c[3] * e[2:].cpu()
+    torch.testing.assert_close(xb.cpu(), want, rtol=1e-5, atol=1e-5)
