@@ -113,6 +113,13 @@ __global__ void add_noise_kernel(const float* __restrict__ x, const float* __res
   out[idx] = coef[2 * b] * x[idx] + coef[2 * b + 1] * nz[idx];
 }
 
+// Holds the stream busy for ~us microseconds (one wave polling the 100 MHz real-time counter).  Measurement aid: lets a
+// host that enqueues slower than the GPU executes build up a queue, so per-kernel event pairs time kernels, not host gaps.
+__global__ void sleep_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -159,6 +166,12 @@ extern "C" int aldm_add_noise(const float* x, const float* noise, const float* c
   ALDM_CHECK_ARG(x && noise && coef && out && B > 0 && n_per_sample > 0, "add_noise: bad args");
   hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x, noise, coef, B, n_per_sample, out);
   return aldm_launch_status("add_noise");
+}
+
+extern "C" int aldm_sleep_us(int us, void* stream) {
+  ALDM_CHECK_ARG(us > 0 && us <= 2000000, "sleep_us: 0 < us <= 2e6");
+  hipLaunchKernelGGL(sleep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)us * 100ull);
+  return aldm_launch_status("sleep_us");
 }
 
 extern "C" int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream) {

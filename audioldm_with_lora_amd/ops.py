@@ -392,6 +392,10 @@ def add_noise(x, noise, coef):
     return out.to(x.dtype)
 
 
+def sleep_us(us):
+    check(_lib.load().aldm_sleep_us(int(us), _stream()), "aldm_sleep_us")
+
+
 def advance_step(step_idx, timesteps_f32, t_out):
     check(_lib.load().aldm_advance_step(_p(step_idx), _p(timesteps_f32), timesteps_f32.numel(), _p(t_out), _stream()),
           "aldm_advance_step")

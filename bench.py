@@ -52,9 +52,10 @@ def synth_inputs(batch, height, width, seed_off=0):
 
 
 def kernel_profile(engine, fine=False):
-    """One eager denoise step with an event pair around every launch; returns per-kernel-variant totals."""
+    """One eager denoise step with an event pair (on the launch stream) around every launch; returns per-kernel totals."""
     from audioldm_with_lora_amd import ops
     ops.PROFILE = []
+    ops.sleep_us(60000)          # queue the whole step behind a 60 ms sleep: event pairs then time kernels, not host gaps
     engine._one_step()
     torch.cuda.synchronize()
     rows, ops.PROFILE = ops.PROFILE, None

@@ -159,6 +159,8 @@ int aldm_f32_to_bf16(const float* x, long long n, float mul, void* y, void* stre
    x (fp32, [B][n]) is updated in place; x_in (bf16, [2B][n] if cfg else [B][n]) receives the next UNet input. */
 int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance,
                        const float* coef, const int* step_idx, void* x_in_bf16, void* stream);
+/* measurement aid: keeps `stream` busy for ~us microseconds so that later launches queue up behind it (bench.py) */
+int aldm_sleep_us(int us, void* stream);
 /* device-side loop counter for graph replay: step_idx[0] = (step_idx[0] + 1) mod n_steps ; t_out[0] = timesteps[step_idx[0]] */
 int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream);
 
