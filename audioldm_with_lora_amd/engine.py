@@ -16,7 +16,7 @@ from . import ops
 
 class DenoiseEngine:
     def __init__(self, unet, scheduler, batch, height, width, num_inference_steps, guidance_scale=2.5,
-                 device="cuda", use_graph=True):
+                 device="cuda", use_graph=True, chains=None):
         self.unet, self.scheduler = unet, scheduler
         self.B, self.H, self.W = batch, height, width
         self.C = unet.cfg["in_channels"]
@@ -29,45 +29,77 @@ class DenoiseEngine:
         scheduler.set_timesteps(num_inference_steps)
         self.timesteps_f32 = scheduler.timesteps.to(torch.float32).to(dev)
         self.coef = scheduler.coefficient_table().contiguous().to(dev)
-        nb = 2 * batch if self.cfg else batch
+        # Optional: independent sub-batches ("chains") captured as parallel branches of the graph (each owns a contiguous
+        # slice of the latents and its own CFG-doubled input block [uncond_i | cond_i]).  Measured on MI355X / ROCm 7.2 at
+        # batch 4: 1 chain 4.83 ms/step, 2 chains 4.81, 4 chains 5.90 -- the branches do not overlap usefully, so the
+        # default stays a single chain.
+        if chains is None:
+            chains = 1
+        assert batch % chains == 0
+        self.chains, self.bc = chains, batch // chains
+        nbc = 2 * self.bc if self.cfg else self.bc
         self.x = torch.zeros(batch, height, width, self.C, dtype=torch.float32, device=dev)       # latents, NHWC fp32
-        self.x_in = torch.zeros(nb, height, width, self.C, dtype=torch.bfloat16, device=dev)      # UNet input
+        self.x_in = [torch.zeros(nbc, height, width, self.C, dtype=torch.bfloat16, device=dev) for _ in range(chains)]
         self.t_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
         self.cls = None
         self.graph = None
+        self._side = None
 
     def set_condition(self, prompt_embeds, negative_prompt_embeds=None):
         """[B, D] L2-normalised prompt embeddings (CLAP text_embeds); CFG order is [negative | positive]."""
         pe = prompt_embeds.to(self.dev, torch.float32)
+        ne = None
         if self.cfg:
             ne = torch.zeros_like(pe) if negative_prompt_embeds is None else negative_prompt_embeds.to(self.dev, torch.float32)
-            pe = torch.cat([ne, pe])
-        cls = ops.f32_to_bf16(pe.contiguous())
+        new = []
+        for i in range(self.chains):
+            sl = slice(i * self.bc, (i + 1) * self.bc)
+            e = torch.cat([ne[sl], pe[sl]]) if self.cfg else pe[sl]
+            new.append(ops.f32_to_bf16(e.contiguous()))
         if self.cls is None:
-            self.cls = cls
+            self.cls = new
         else:
-            self.cls.copy_(cls)
+            for dst, src in zip(self.cls, new):
+                dst.copy_(src)
 
     def set_latents(self, latents_nchw):
         """latents [B, C, H, W] fp32 (already multiplied by init_noise_sigma = 1)."""
         x = ops.nchw_to_nhwc(latents_nchw.to(self.dev, torch.float32).contiguous(), out_f32=True)
         self.x.copy_(x)
         xb = ops.f32_to_bf16(self.x)
-        self.x_in[: self.B].copy_(xb)
-        if self.cfg:
-            self.x_in[self.B:].copy_(xb)
+        for i in range(self.chains):
+            sl = slice(i * self.bc, (i + 1) * self.bc)
+            self.x_in[i][: self.bc].copy_(xb[sl])
+            if self.cfg:
+                self.x_in[i][self.bc:].copy_(xb[sl])
         self.step_idx.zero_()
         self.t_buf.copy_(self.timesteps_f32[:1])
 
+    def _chain_step(self, i):
+        eps = self.unet.forward_nhwc(self.x_in[i], self.t_buf, self.cls[i])
+        ops.cfg_ddim_step(eps, self.x[i * self.bc:(i + 1) * self.bc], self.cfg, self.g, self.coef, self.step_idx, self.x_in[i])
+
     def _one_step(self):
-        eps = self.unet.forward_nhwc(self.x_in, self.t_buf, self.cls)
-        ops.cfg_ddim_step(eps, self.x, self.cfg, self.g, self.coef, self.step_idx, self.x_in)
+        if self.chains == 1:
+            self._chain_step(0)
+        else:                                   # fork / join: under capture these become parallel graph branches
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = [torch.cuda.Stream() for _ in range(self.chains - 1)]
+            for s in self._side:
+                s.wait_stream(cur)
+            self._chain_step(0)
+            for i, s in enumerate(self._side):
+                with torch.cuda.stream(s):
+                    self._chain_step(i + 1)
+            for s in self._side:
+                cur.wait_stream(s)
         ops.advance_step(self.step_idx, self.timesteps_f32, self.t_buf)
 
     def capture(self):
         """Warm up (loads code objects, sizes the split-K workspace) and capture one step."""
-        saved = (self.x.clone(), self.x_in.clone(), self.step_idx.clone(), self.t_buf.clone())
+        saved = (self.x.clone(), [t.clone() for t in self.x_in], self.step_idx.clone(), self.t_buf.clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -79,7 +111,7 @@ class DenoiseEngine:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._one_step()
-        for dst, src in zip((self.x, self.x_in, self.step_idx, self.t_buf), saved):
+        for dst, src in zip([self.x] + self.x_in + [self.step_idx, self.t_buf], [saved[0]] + saved[1] + [saved[2], saved[3]]):
             dst.copy_(src)
         torch.cuda.synchronize()
 

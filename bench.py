@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--rank", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--chains", type=int, default=None, help="independent sub-batch chains captured as parallel graph branches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the short LoRA-training measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -207,7 +208,7 @@ def main():
 
     H, W, NSTEPS, G = 250, 16, 200, 2.5
     unet, _ = build_unet(args.rank)
-    eng = DenoiseEngine(unet, DDIMScheduler(), args.batch, H, W, NSTEPS, G, use_graph=not args.no_graph)
+    eng = DenoiseEngine(unet, DDIMScheduler(), args.batch, H, W, NSTEPS, G, use_graph=not args.no_graph, chains=args.chains)
     lat, pe, ne = synth_inputs(args.batch, H, W, seed_off=100 * rank)
     eng.set_condition(pe, ne)
     eng.set_latents(lat)
@@ -270,7 +271,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "audioldm-s-full-v2 UNet + rank-%d LoRA (q,k,v,out), DDIM 200-step schedule, "
                                    "batch %d x 10 s clips (latent 250x16), CFG 2.5 (UNet batch %d), bf16" % (args.rank, args.batch, 2 * args.batch),
-                       "per_gpu_batch": args.batch, "parallelism": f"prompt-sharded x{world}", "hip_graph": not args.no_graph,
+                       "per_gpu_batch": args.batch, "parallelism": f"prompt-sharded x{world}", "hip_graph": not args.no_graph, "graph_chains": eng.chains,
                        "sample_steps_per_sec": round(world * args.steps * args.batch / dt, 2)},
             "roofline": roofline,
         }
