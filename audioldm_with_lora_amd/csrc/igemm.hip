@@ -9,6 +9,7 @@ int aldm_launch_tile_128x128(const IgemmDev& d, int Rp, bool vt, int ring, hipSt
 int aldm_launch_tile_128x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_64x128(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_64x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_128x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 
 static int pick_tile(int M, int N) {
   auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
@@ -95,6 +96,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_128x64: rc = aldm_launch_tile_128x64(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_64x128: rc = aldm_launch_tile_64x128(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_64x64: rc = aldm_launch_tile_64x64(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;
   }
   if (rc != ALDM_OK) return rc;

@@ -213,7 +213,7 @@ struct EpiCfg {
   static constexpr int BYTES = (BM * LD > BN * LDT ? BM * LD : BN * LDT) * 4;
 };
 
-template <int BM, int BN, int MI, int NI, bool VT>
+template <int BM, int BN, int MI, int NI, bool VT, int NT = 256>
 __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], char* smem, bool vt_wg, int m0,
                                                int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid,
                                                const float* lnst = nullptr) {
@@ -237,7 +237,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
 
   if (VT && vt_wg) {
     // rows of the image are channels n, columns are pixels: vt[b][n - col0][pix .. pix+7]
-    for (int g = tid; g < BN * (BM / 8); g += THREADS) {
+    for (int g = tid; g < BN * (BM / 8); g += NT) {
       const int rn = g / (BM / 8), cm = (g - rn * (BM / 8)) * 8;
       const int n = n0 + rn, m = m0 + cm;
       if (n >= p.N || m >= p.M) continue;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     return;
   }
   if (p.splits > 1) {
-    for (int g = tid; g < BM * (BN / 8); g += THREADS) {
+    for (int g = tid; g < BM * (BN / 8); g += NT) {
       const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
       const int m = m0 + r, n = n0 + c;
       if (m >= p.M || n >= p.N) continue;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   }
   if (p.geglu) {
     // image columns come in blocks of (16 value | 16 gate); 8 output columns = 8 values and their 8 gates
-    for (int g = tid; g < BM * (BN / 16); g += THREADS) {
+    for (int g = tid; g < BM * (BN / 16); g += NT) {
       const int r = g / (BN / 16), jo = (g - r * (BN / 16)) * 8;        // jo: output column inside the tile
       const int cv = ((jo >> 4) << 5) + (jo & 15);                       // value column inside the tile
       const int m = m0 + r, nv = n0 + cv;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
     return;
   }
-  for (int g = tid; g < BM * (BN / 8); g += THREADS) {
+  for (int g = tid; g < BM * (BN / 8); g += NT) {
     const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
     const int m = m0 + r, n = n0 + c;
     if (m >= p.M || n >= p.N) continue;
@@ -574,15 +574,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 #endif
 
 template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
-__global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef ALDM_DIAG
   unsigned long long dg_t_entry; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_entry) :: "memory");
 #endif
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+  constexpr int NT = 64 * WM * WN;               // threads per workgroup
+  constexpr int RPP = NT / 8;                    // tile rows covered by one DMA pass of the whole workgroup
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr int BROWS = BN + RP;
-  constexpr int A_PASSES = BM / 32, W_PASSES = BN / 32, B_PASSES = BROWS / 32;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && BROWS % RPP == 0, "tile rows must be whole DMA passes");
+  constexpr int A_PASSES = BM / RPP, W_PASSES = BN / RPP, B_PASSES = BROWS / RPP;
   constexpr int L = A_PASSES + B_PASSES;   // LDS-DMA instructions per thread per K-tile
   constexpr int D = S - 1;                 // K-tiles in flight ahead of the MFMAs
   constexpr int STAGE = (BM + BROWS) * 128;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES];
 #pragma unroll
   for (int ps = 0; ps < A_PASSES; ++ps) {
-    const int m = min(m0 + rbase + 32 * ps, p.M - 1);
+    const int m = min(m0 + rbase + RPP * ps, p.M - 1);
     const int b = fdiv(m, p.fd_ohw);
     const int pix = m - b * p.OHW;
     const int oh = fdiv(pix, p.fd_ow), ow = pix - oh * p.OW;
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   unsigned b_off[B_PASSES];
 #pragma unroll
   for (int ps = 0; ps < B_PASSES; ++ps) {
-    const int r = rbase + 32 * ps;
+    const int r = rbase + RPP * ps;
     const int row = ps < W_PASSES ? min(n0 + r, p.N - 1) : r - BN;
     b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
   }
@@ -684,18 +687,18 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
     if (src2) {
 #pragma unroll
       for (int ps = 0; ps < A_PASSES; ++ps)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * 4096), 16, cur_off[ps], a_soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, cur_off[ps], a_soff, 0, 0);
     } else {
 #pragma unroll
       for (int ps = 0; ps < A_PASSES; ++ps)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + ps * 4096), 16, cur_off[ps], a_soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, cur_off[ps], a_soff, 0, 0);
     }
 #pragma unroll
     for (int ps = 0; ps < B_PASSES; ++ps) {
       if (ps < W_PASSES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * 128 + ps * 4096), 16, b_off[ps], b_soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * 128 + ps * (RPP * 128)), 16, b_off[ps], b_soff, 0, 0);
       else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_la, (lds_ptr_t)(sbase + BM * 128 + ps * 4096), 16, b_off[ps], b_soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_la, (lds_ptr_t)(sbase + BM * 128 + ps * (RPP * 128)), 16, b_off[ps], b_soff, 0, 0);
     }
     if (live) {   // advance the scalar cursor by one K-tile
       s_c0 += BK;
@@ -769,9 +772,9 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
     const __amdgpu_buffer_rsrc_t rs_lb = make_rsrc(p.lora_b, p.lb_bytes);
 #pragma unroll
     for (int ps = 0; ps < W_PASSES; ++ps) {
-      const int row = min(n0 + rbase + 32 * ps, p.N - 1);
+      const int row = min(n0 + rbase + RPP * ps, p.N - 1);
       const unsigned off = (kchunk < RP / 8) ? (unsigned)row * (unsigned)(RP * 2) + kchunk * 16 : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lb, (lds_ptr_t)(LBs + wave * 1024 + ps * 4096), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lb, (lds_ptr_t)(LBs + wave * 1024 + ps * (RPP * 128)), 16, off, 0, 0, 0);
     }
   }
 #pragma unroll
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
   // s_n = sum_k W'_nk, c_n = beta . W_n (+ bias).  The row statistics come from the SAME activation tiles the MFMAs consume:
   // TPR threads per row sum their share of every landed K-tile out of LDS -- no separate LayerNorm launch, no normalised
   // tensor in HBM.
-  constexpr int TPR = THREADS / BM;                       // threads per tile row
+  constexpr int TPR = NT / BM;                       // threads per tile row
   constexpr int CPT = 8 / TPR;                            // 16-byte chunks of a 64-wide K-tile per thread
   const bool lnf = p.ln_s != nullptr;
   const int ln_row = tid / TPR, ln_c0 = (tid % TPR) * CPT;
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(THREADS) void igemm_pipe_kernel(const IgemmDev p) {
       else mma_step(std::false_type{}, smem, LBs, ks, false);
     }
   }
-  igemm_epilogue<BM, BN, MI, NI, VT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
+  igemm_epilogue<BM, BN, MI, NI, VT, NT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
 #ifdef ALDM_DIAG
   if (p.diag && lane == 0) {
     unsigned long long dg_t_end; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_end) :: "memory");
@@ -945,7 +948,7 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   IgemmDev dd = d;
   dd.tiles_n = cdiv(d.N, BN);
   dim3 grid(cdiv(d.M, BM) * dd.tiles_n, 1, d.splits);
-  hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, st, dd);
+  hipLaunchKernelGGL(kern, grid, dim3(S == 0 ? THREADS : 64 * WM * WN), lds, st, dd);
   return aldm_launch_status("igemm");
 }
 

@@ -157,8 +157,11 @@ def auto_splits(M, N, ktiles):
 
 
 def pick_tile(M, N):
-    """Tile heuristic from tools/bench_igemm.py sweeps on MI355X: 128x64 once it still yields >= ~2 workgroups
-    per CU (256 CUs), else 64x64 (more, smaller workgroups hide the short K loops of the low-res levels)."""
+    """Tile heuristic from tools/bench_igemm.py sweeps on MI355X: the 8-wave 128x128 tile once it still yields ~2
+    workgroups per CU (256 CUs), 128x64 down to ~2 per CU, else 64x64 (more, smaller workgroups hide the short K loops
+    of the low-resolution levels)."""
+    if N >= 256 and N % 128 == 0 and math.ceil(M / 128) * (N // 128) >= 448:
+        return 6
     if N > 64 and math.ceil(M / 128) * math.ceil(N / 64) >= 448:
         return _lib.TILE_128x64
     if N <= 64 and M >= 4096:
@@ -166,7 +169,7 @@ def pick_tile(M, N):
     return _lib.TILE_64x64
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event).
 # Events are recorded on the stream the kernel is launched on.
@@ -272,13 +275,15 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         a.workspace = ws.data_ptr()
     if tile == 0:
         tile = _lib.TILE_64x64 if pw.Rp else pick_tile(M, pw.N)      # LoRA GEMMs are short-K: favour many workgroups
+        if tile == 6 and (pw.Cin % 64 or (x2 is not None and x2.shape[3] % 64) or in_act or vt is not None):
+            tile = _lib.TILE_128x64                                     # the 8-wave tile only exists on the LDS-DMA path
     a.tile = tile
     if not ring:
-        bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128)}[tile]
+        bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128)}[tile]
         nwg = math.ceil(M / bm) * math.ceil(pw.N / bn) * max(1, splits)
         # few workgroups (low-resolution levels): nothing else hides the HBM latency of the weight stream -> deepest ring;
         # many workgroups: occupancy matters more than depth (tools/bench_igemm.py sweeps)
-        ring = 4 if nwg <= 512 else (2 if ktiles <= 24 else 3)
+        ring = 2 if tile == 6 else (4 if nwg <= 512 else (2 if ktiles <= 24 else 3))
     a.ring = ring
     ktot = KH * KW * pw.Cin
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)

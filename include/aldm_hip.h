@@ -93,7 +93,7 @@ typedef struct {
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
-       ALDM_TILE_32x64 = 5 };
+       ALDM_TILE_32x64 = 5, ALDM_TILE_128x128_W8 = 6 /* 8-wave workgroup */ };
 
 int aldm_igemm(const aldm_igemm_t* p, void* stream);
 size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p);

@@ -136,7 +136,7 @@ def test_packing_layouts():
     ops.attach_lora(lin, [(0, 16, torch.ones(4, 64), torch.ones(16, 4), 2.0), (16, 16, torch.ones(8, 64), torch.ones(16, 8), 1.0)])
     assert lin.Rp == 32 and lin.lora_a.shape == (32, 64) and lin.lora_b.shape == (32, 32)
     assert float(lin.lora_b[0, 0]) == 2.0 and float(lin.lora_b[0, 4]) == 0.0 and float(lin.lora_b[16, 4]) == 1.0
-    assert ops.pick_tile(32000, 128) == 3 and ops.pick_tile(512, 640) == 2
+    assert ops.pick_tile(32000, 128) == 3 and ops.pick_tile(512, 640) == 2 and ops.pick_tile(32000, 256) == 6
     assert ops.auto_splits(512, 640, 90) == 4 and ops.auto_splits(32000, 128, 18) == 1
 
 

@@ -248,3 +248,16 @@ def test_layernorm_folded_into_gemm(ops, M, Cc, N, r, geglu):
         want = want[:, :N // 2] * F.gelu(want[:, N // 2:])
     got = ops.linear(x.to(torch.bfloat16).to(DEV), pw)
     close(got, want, rtol=2e-2)
+
+
+@pytest.mark.parametrize("ring", [2, 3])
+def test_conv3x3_eight_wave_tile(ops, ring):
+    g = torch.Generator().manual_seed(31)
+    x = bf(torch.randn(2, 128, 50, 16, generator=g))
+    x2 = bf(torch.randn(2, 64, 50, 16, generator=g))
+    w = bf(torch.randn(192, 192, 3, 3, generator=g) / math.sqrt(9 * 192))
+    b = torch.randn(192, generator=g)
+    r = bf(torch.randn(2, 192, 50, 16, generator=g))
+    want = F.conv2d(torch.cat([x, x2], 1), w, b, padding=1) + r
+    y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=6, ring=ring)
+    close(to_nchw(y), want)
