@@ -275,8 +275,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         a.workspace = ws.data_ptr()
     if tile == 0:
         tile = _lib.TILE_64x64 if pw.Rp else pick_tile(M, pw.N)      # LoRA GEMMs are short-K: favour many workgroups
-        if tile == 6 and (pw.Cin % 64 or (x2 is not None and x2.shape[3] % 64) or in_act or vt is not None):
-            tile = _lib.TILE_128x64                                     # the 8-wave tile only exists on the LDS-DMA path
+        if tile == 6 and (pw.Cin % 64 or (x2 is not None and x2.shape[3] % 64) or in_act or vt is not None or ktiles < 16):
+            tile = _lib.TILE_128x64           # the 8-wave tile only exists on the LDS-DMA path and only pays on deep K loops
     a.tile = tile
     if not ring:
         bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128)}[tile]

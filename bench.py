@@ -83,12 +83,9 @@ def traffic_from_profile(label):
     prof = json.load(open(files[-1]))
     bm, bn, rp, vt = m.group(1), m.group(2), m.group(3), "true" if m.group(4) else "false"
     tot = n = 0
-    for k, v in prof.items():
-        km = re.match(r"igemm_pipe_kernel<(\d+), (\d+), 2, 2, (\d+), (\w+), (\d+)>", k)
+    for k, v in prof.items():       # every ring depth / wave count of the tile family (split-K launches share the kernel)
+        km = re.match(r"igemm_pipe_kernel<(\\d+), (\\d+), \\d+, \\d+, (\\d+), (\\w+), (\\d+)>", k)
         if km and (km.group(1), km.group(2), km.group(3), km.group(4)) == (bm, bn, rp, vt):
-            # the split-K label is separate in the live profile; ring depth 3 is what the split-K launches use
-            if ("_sk" in label) != (km.group(5) == "3" and bm == "64"):
-                continue
             tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
             n += v["launches_sampled"]
     return (tot / n if n else None), os.path.basename(files[-1])
