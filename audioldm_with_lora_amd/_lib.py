@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALDM_LIB") or os.path.join(_HERE, "libaldm_hip.so")   # ALDM_LIB: diagnostic builds only
 
-ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4
 OUT_BF16, OUT_F32 = 0, 1
 TILE_AUTO, TILE_128x128, TILE_64x64, TILE_128x64, TILE_64x128 = 0, 1, 2, 3, 4
 
@@ -59,6 +59,11 @@ PROTOTYPES = {
                                  C.c_void_p]),
     "aldm_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_attention_varlen": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p]),
+    "aldm_embed_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_attention_lse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p]),

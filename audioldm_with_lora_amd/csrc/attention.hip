@@ -30,7 +30,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
                                                             const bf16* __restrict__ k, int ldk,
                                                             const bf16* __restrict__ vt, int vt_ld, long long vt_bs,
                                                             int N, int D, float c /* scale*log2(e) */,
-                                                            bf16* __restrict__ out, int out_ld, float* __restrict__ lse) {
+                                                            bf16* __restrict__ out, int out_ld, float* __restrict__ lse,
+                                                            const int* __restrict__ kv_len) {
   using Cfg = AttnCfg<DP>;
   constexpr int T = 64 * NW;
   constexpr int DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS;
@@ -50,6 +51,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   const bf16* kb = k + (long long)b * N * ldk + head * D;
   const bf16* vb = vt + (long long)b * vt_bs + (long long)head * D * vt_ld;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // keys 0 .. Nk-1 of this batch item take part (right-padded text batches pass their true lengths; the key loop
+  // then stops at the last valid tile instead of masking 512-token padding)
+  const int Nk = kv_len ? max(1, min(kv_len[b], N)) : N;
+  if (kv_len && (int)blockIdx.x * NW * 32 >= Nk) {
+    // every query of this workgroup is padding: its rows are never read as keys, so write zeros and leave
+    for (int i = tid; i < NW * 32 * (D / 4); i += T) {
+      const int row = blockIdx.x * NW * 32 + i / (D / 4), c4 = i % (D / 4);
+      if (row < N) *reinterpret_cast<uint2*>(out + ((long long)b * N + row) * out_ld + head * D + c4 * 4) = make_uint2(0u, 0u);
+    }
+    return;
+  }
 
   // zero the d-padding rows of both V^T buffers once (rows D .. DT*32-1 stay zero for the whole kernel)
   {
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       const int cidx = tid + i * T;
       const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
       bf16x8 v = zero8;
-      if (cidx < KCH && kv0 + row < N && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(kb + (long long)(kv0 + row) * ldk + ch * 8);
+      if (cidx < KCH && kv0 + row < Nk && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(kb + (long long)(kv0 + row) * ldk + ch * 8);
       kreg[i] = v;
     }
 #pragma unroll
@@ -84,11 +96,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       const int row = cidx >> 3, ch = cidx & 7;
       bf16x8 v = zero8;
       const int kvb = kv0 + ch * 8;
-      if (cidx < VCH && row < D && kvb < N) {
+      if (cidx < VCH && row < D && kvb < Nk) {
         v = *reinterpret_cast<const bf16x8*>(vb + (long long)row * vt_ld + kvb);
-        if (kvb + 8 > N) {
+        if (kvb + 8 > Nk) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) if (kvb + j >= N) v[j] = (bf16)0.f;
+          for (int j = 0; j < 8; ++j) if (kvb + j >= Nk) v[j] = (bf16)0.f;
         }
       }
       vreg[i] = v;
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (N + KV - 1) / KV;
+  const int ntiles = (Nk + KV - 1) / KV;
   prefetch(0);
   stage(0);
   __syncthreads();
@@ -143,13 +155,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
       }
     }
-    if (kv0 + KV > N) {  // tail tile: mask keys >= N
+    if (kv0 + KV > Nk) {  // tail tile: mask keys >= Nk
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int kvr = kv0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kvr >= N) s[sub][i] = -INFINITY;
+          if (kvr >= Nk) s[sub][i] = -INFINITY;
         }
     }
     // ---- online softmax (lane-local: this lane's query column) ----
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 
 template <int DP, int NW>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
-                int H, int D, float scale, void* out, int out_ld, float* lse, hipStream_t st) {
+                int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   using Cfg = AttnCfg<DP>;
   auto kern = attention_kernel<DP, NW>;
   static bool attr_done = false;
@@ -227,17 +239,17 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, 
   attr_done = true;
   dim3 grid(cdiv(N, 32 * NW), H, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), Cfg::LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt,
-                     vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld, lse);
+                     vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld, lse, kv_len);
   return aldm_launch_status("attention");
 }
 
 template <int DP>
 int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
-                  int H, int D, float scale, void* out, int out_ld, float* lse, hipStream_t st) {
+                  int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   // measured at N = 1000, d = 32: 128-query workgroups (4 waves) 31 us vs 64-query 40 us
-  if (N >= 512) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, st);
-  if (N >= 128) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, st);
-  return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, st);
+  if (N >= 512) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
+  if (N >= 128) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
+  return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
 }
 
 // ---- row softmax (VAE mid-block attention runs QK^T / PV through the GEMM kernel) ----
@@ -266,13 +278,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 static int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                           long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
-                          float* lse, void* stream) {
+                          float* lse, const int* kv_len, void* stream) {
   ALDM_CHECK_ARG(q && k && vt && out, "attention: null pointer");
   ALDM_CHECK_ARG(B > 0 && N > 0 && H > 0 && d > 0, "attention: bad dims");
   ALDM_CHECK_ARG(d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0, "attention: d/ld must be multiples of 8");
   ALDM_CHECK_ARG(vt_ld >= ((N + 7) / 8) * 8, "attention: vt_ld %d too small for N %d", vt_ld, N);
   hipStream_t st = (hipStream_t)stream;
-#define ALDM_ATTN(DPV) return launch_attn_d<DPV>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, st)
+#define ALDM_ATTN(DPV) return launch_attn_d<DPV>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, kv_len, st)
   if (d <= 16) ALDM_ATTN(16);
   if (d <= 32) ALDM_ATTN(32);
   if (d <= 48) ALDM_ATTN(48);
@@ -286,14 +298,21 @@ static int attention_impl(const void* q, int ldq, const void* k, int ldk, const 
 extern "C" int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                               long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                               void* stream) {
-  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, stream);
+  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, nullptr, stream);
 }
 
 extern "C" int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                                   long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                                   float* lse, void* stream) {
   ALDM_CHECK_ARG(lse, "attention_lse: null lse");
-  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, stream);
+  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, nullptr, stream);
+}
+
+extern "C" int aldm_attention_varlen(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                                     long long vt_batch_stride, int B, int N, int H, int d, float scale,
+                                     const int* kv_len, void* out, int out_ld, void* stream) {
+  ALDM_CHECK_ARG(kv_len, "attention_varlen: null kv_len");
+  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, kv_len, stream);
 }
 
 extern "C" int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out,

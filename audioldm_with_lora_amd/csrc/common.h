@@ -41,6 +41,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     case ALDM_ACT_SILU: return silu_f(v);
     case ALDM_ACT_LRELU: return v > 0.f ? v : v * slope;
     case ALDM_ACT_TANH: return tanhf(v);
+    case ALDM_ACT_GELU: return gelu_erf_f(v);
     default: return v;
   }
 }

@@ -199,6 +199,71 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
   }
 }
 
+// RoBERTa-style embedding sum + LayerNorm for the CLAP text tower: one wave per token.
+//   e = word[id] + type[0] + pos[pid],  pid = pad + (id != pad ? #{i <= j : ids[b][i] != pad} : 0)
+// (fairseq make_positions, as transformers ClapTextEmbeddings.create_position_ids_from_input_ids).  fp32 tables,
+// fp32 statistics, bf16 activations out.
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(const long long* __restrict__ ids, int M, int L, int C,
+                                                              const float* __restrict__ word, int vocab,
+                                                              const float* __restrict__ pos, int npos,
+                                                              const float* __restrict__ type0,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int pad,
+                                                              bf16* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int b = row / L, j = row - b * L;
+  const long long* idr = ids + (long long)b * L;
+  int cnt = 0;
+  for (int i = lane; i <= j; i += 64) cnt += idr[i] != pad;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  long long id = idr[j];
+  int pid = pad + (id != pad ? cnt : 0);
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // ids are validated on the host; clamp keeps the read in bounds
+  pid = pid >= npos ? npos - 1 : pid;
+  const float* wr = word + id * C;
+  const float* pr = pos + (long long)pid * C;
+  const int nch = C >> 3;
+  float v[LN_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wr + ch * 8 + 4 * h);
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + ch * 8 + 4 * h);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(type0 + ch * 8 + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[i][4 * h + k] = a[k] + t4[k] + p4[k]; s += v[i][4 * h + k]; }
+      }
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; ss += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  bf16* yr = y + (long long)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (bf16)((v[i][k] - mean) * rstd * gamma[ch * 8 + k] + beta[ch * 8 + k]);
+      *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2, int groups, float eps,
@@ -237,4 +302,16 @@ extern "C" int aldm_layernorm(const void* x, int M, int C, const float* gamma, c
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, M, C, gamma,
                      beta, eps, (bf16*)y);
   return aldm_launch_status("layernorm");
+}
+
+extern "C" int aldm_embed_layernorm(const long long* ids, int B, int L, int C, const float* word, int vocab,
+                                    const float* pos, int npos, const float* type0, const float* gamma,
+                                    const float* beta, float eps, int pad_idx, void* y, void* stream) {
+  ALDM_CHECK_ARG(ids && word && pos && type0 && gamma && beta && y && B > 0 && L > 0, "embed_layernorm: null pointer / bad dims");
+  ALDM_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "embed_layernorm: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXC);
+  ALDM_CHECK_ARG(vocab > 0 && npos > pad_idx + 1 && L + pad_idx + 1 <= npos, "embed_layernorm: %d tokens do not fit %d positions (pad %d)", L, npos, pad_idx);
+  const int M = B * L;
+  hipLaunchKernelGGL(embed_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ids, M, L, C, word, vocab,
+                     pos, npos, type0, gamma, beta, eps, pad_idx, (bf16*)y);
+  return aldm_launch_status("embed_layernorm");
 }

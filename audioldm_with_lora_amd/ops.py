@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_SILU, ACT_TANH, OUT_BF16, OUT_F32, IgemmArgs, check)
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, ACT_TANH, OUT_BF16, OUT_F32, IgemmArgs, check)
 
 BK = 64
 
@@ -325,8 +325,9 @@ def layernorm(x2d, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(qk, vt, B, N, H, d, out=None):
-    """qk [B*N, 2C] (Q | K), vt [B, C, Npad]; returns [B*N, C]."""
+def attention(qk, vt, B, N, H, d, out=None, kv_len=None):
+    """qk [B*N, 2C] (Q | K), vt [B, C, Npad]; returns [B*N, C].  kv_len: optional int32 [B] valid-key counts
+    (right-padded batches)."""
     _require_gpu(qk)
     Cc = H * d
     if out is None:
@@ -334,10 +335,30 @@ def attention(qk, vt, B, N, H, d, out=None):
     q_ptr = C.c_void_p(qk.data_ptr())
     k_ptr = C.c_void_p(qk.data_ptr() + Cc * 2)
     lib = _lib.load()
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_cuda
+        check(_launch(f"attention_varlen_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention_varlen(
+            q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
+            _p(kv_len), _p(out), Cc, _stream())), "aldm_attention_varlen")
+        return out
     check(_launch(f"attention_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention(
         q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
         _p(out), Cc, _stream())), "aldm_attention")
     return out
+
+
+def embed_layernorm(ids, word, pos, type0, gamma, beta, eps, pad_idx):
+    """ids int64 [B, L] (device) -> LayerNorm(word[ids] + type0 + pos[position_ids]) as bf16 [B*L, C]."""
+    _require_gpu(ids)
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    B, L = ids.shape
+    Cc = word.shape[1]
+    for t in (word, pos, type0, gamma, beta):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    y = torch.empty(B * L, Cc, dtype=torch.bfloat16, device=ids.device)
+    check(_lib.load().aldm_embed_layernorm(_p(ids), B, L, Cc, _p(word), word.shape[0], _p(pos), pos.shape[0], _p(type0),
+                                           _p(gamma), _p(beta), eps, pad_idx, _p(y), _stream()), "aldm_embed_layernorm")
+    return y
 
 
 def softmax_rows(s, scale, cols, ld_out):

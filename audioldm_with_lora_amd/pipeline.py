@@ -46,7 +46,8 @@ class AudioLDMPipeline:
         scheduler = DDIMScheduler.from_pretrained(path, subfolder="scheduler")
         text_encoder = tokenizer = None
         if os.path.isdir(os.path.join(path, "text_encoder")):
-            from transformers import ClapTextModelWithProjection, RobertaTokenizerFast
+            from transformers import RobertaTokenizerFast          # host-side string -> ids only
+            from .clap_text import ClapTextModelWithProjection    # the tower itself runs on the HIP kernels
             text_encoder = ClapTextModelWithProjection.from_pretrained(os.path.join(path, "text_encoder"))
             tokenizer = RobertaTokenizerFast.from_pretrained(os.path.join(path, "tokenizer"))
         return cls(vae, text_encoder, tokenizer, unet, scheduler, vocoder)
@@ -62,7 +63,7 @@ class AudioLDMPipeline:
     def set_progress_bar_config(self, **kw):
         self._progress = kw
 
-    # ---- step 2: prompt -> L2-normalised CLAP text embedding (host code, not on the north_star path) ----
+    # ---- step 2: prompt -> L2-normalised CLAP text embedding (tokeniser on the host, tower on the GPU: clap_text.py) ----
     def _encode_prompt(self, prompt, batch):
         if self.text_encoder is None or self.tokenizer is None:
             raise ValueError("no text encoder loaded: pass prompt_embeds= / negative_prompt_embeds=")

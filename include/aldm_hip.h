@@ -31,7 +31,7 @@ extern "C" {
 #define ALDM_E_ALIGN (-2)    /* channel counts or pointers not 16-byte friendly */
 #define ALDM_E_UNSUPPORTED (-3)
 
-enum { ALDM_ACT_NONE = 0, ALDM_ACT_SILU = 1, ALDM_ACT_LRELU = 2, ALDM_ACT_TANH = 3 };
+enum { ALDM_ACT_NONE = 0, ALDM_ACT_SILU = 1, ALDM_ACT_LRELU = 2, ALDM_ACT_TANH = 3, ALDM_ACT_GELU = 4 /* exact erf GELU */ };
 enum { ALDM_OUT_BF16 = 0, ALDM_OUT_F32 = 1 };
 
 const char* aldm_version(void);
@@ -110,6 +110,12 @@ int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2,
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
 int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,
                    void* stream);
+/* ClapTextEmbeddings: y[b*L+j] = LayerNorm(word[ids[b][j]] + type0 + pos[pid]) as bf16 [B*L][C]; pid counts the non-pad
+   tokens up to and including j (offset by pad_idx; pad tokens use pid = pad_idx).  ids int64 on the device, fp32 tables.
+   First op of `text_encoder(input_ids, attention_mask)` [REF script/train/train_audioldm_lora.py:513-518]. */
+int aldm_embed_layernorm(const long long* ids, int B, int L, int C, const float* word, int vocab, const float* pos,
+                         int npos, const float* type0, const float* gamma, const float* beta, float eps, int pad_idx,
+                         void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash-style multi-head self-attention core (F.scaled_dot_product_attention in diffusers
@@ -122,6 +128,14 @@ int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* v
                    void* stream);
 
 /* Same, additionally writing the log2-domain log-sum-exp of the scaled scores, lse [B][H][N] fp32 (training). */
+/* Same core with a per-batch-item key count kv_len[B] (int32, device): keys >= kv_len[b] are excluded exactly as an
+   additive -inf attention_mask excludes right-padded tokens, and the key loop stops at the last valid tile.  Query
+   rows >= kv_len[b] that fall in all-padding workgroups are written as zeros.  Serves ClapTextSelfAttention under
+   the padding mask of `text_encoder(input_ids, attention_mask)` [REF script/train/train_audioldm_lora.py:513-518]. */
+int aldm_attention_varlen(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                          long long vt_batch_stride, int B, int N, int H, int d, float scale, const int* kv_len,
+                          void* out, int out_ld, void* stream);
+
 int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                        long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                        float* lse, void* stream);

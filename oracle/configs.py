@@ -57,6 +57,27 @@ VOCODER = dict(
 )
 
 
+# text_encoder/config.json of cvssp/audioldm-s-full-v2: ClapTextModelWithProjection (RoBERTa-base tower + 2-layer
+# projection head).  [MEM]; the class itself is importable from the installed transformers, which pins oracle/clap_text.py.
+CLAP_TEXT = dict(
+    vocab_size=50265,
+    hidden_size=768,
+    num_hidden_layers=12,
+    num_attention_heads=12,
+    intermediate_size=3072,
+    max_position_embeddings=514,
+    type_vocab_size=1,
+    pad_token_id=1,
+    layer_norm_eps=1e-12,
+    projection_dim=512,
+)
+
+
+def tiny_clap_text():
+    return dict(CLAP_TEXT, vocab_size=200, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                intermediate_size=128, max_position_embeddings=40, projection_dim=32)
+
+
 def tiny_unet():
     """A shrunken UNet of the same topology for fast CPU/GPU parity tests."""
     c = dict(UNET)

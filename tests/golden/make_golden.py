@@ -7,6 +7,10 @@ Sources of truth (none of them is a reference file):
   * ddim_tables.npz    -- closed-form DDIM known answers, computed here in
                           float64 numpy independently of oracle/ddim.py.
   * poly_lr.npz        -- transformers.optimization.get_polynomial_decay_schedule_with_warmup values.
+  * clap_text_tiny.npz -- transformers.ClapTextModelWithProjection (installed package; the class the reference
+                          calls at [REF script/train/train_audioldm_lora.py:513-518]) with a shrunken config and
+                          seeded weights: weights, right-padded input_ids / attention_mask, text_embeds and
+                          last_hidden_state.
 Run:  python tests/golden/make_golden.py
 """
 import os
@@ -82,7 +86,48 @@ def poly():
     print("poly", vals[:3], vals[-3:])
 
 
+def hf_clap_text(cfg):
+    from transformers import ClapTextConfig, ClapTextModelWithProjection
+    hc = ClapTextConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
+                        num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                        intermediate_size=cfg["intermediate_size"], max_position_embeddings=cfg["max_position_embeddings"],
+                        type_vocab_size=cfg["type_vocab_size"], pad_token_id=cfg["pad_token_id"],
+                        layer_norm_eps=cfg["layer_norm_eps"], projection_dim=cfg["projection_dim"], hidden_act="gelu",
+                        projection_hidden_act="relu")
+    return ClapTextModelWithProjection(hc).eval()
+
+
+def clap_text():
+    from oracle.configs import tiny_clap_text
+    cfg = tiny_clap_text()
+    torch.manual_seed(20250825)
+    m = hf_clap_text(cfg)
+    g = torch.Generator().manual_seed(11)
+    sd = {k: v for k, v in m.state_dict().items() if not k.endswith(("position_ids", "token_type_ids"))}
+    for k, v in sd.items():                     # HF draws N(0, 0.02): re-draw so activations are O(1)
+        if k.endswith("weight") and v.dim() == 2 and "embeddings" not in k:
+            v.copy_(torch.randn(v.shape, generator=g) / v.shape[1] ** 0.5)
+        elif k.endswith("bias"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        elif "embeddings" in k and v.dim() == 2:
+            v.copy_(torch.randn(v.shape, generator=g))
+    m.load_state_dict(sd, strict=False)
+    B, L = 3, 24
+    ids = torch.randint(3, cfg["vocab_size"], (B, L), generator=g)
+    mask = torch.ones(B, L, dtype=torch.long)
+    for b, n in enumerate((24, 9, 1)):
+        ids[b, n:] = cfg["pad_token_id"]
+        mask[b, n:] = 0
+    with torch.no_grad():
+        r = m(input_ids=ids, attention_mask=mask)
+    out = {"w::" + k: v.numpy() for k, v in sd.items()}
+    out.update(input_ids=ids.numpy(), attention_mask=mask.numpy(), text_embeds=r.text_embeds.numpy(),
+               last_hidden_state=r.last_hidden_state.numpy())
+    np.savez_compressed(os.path.join(HERE, "clap_text_tiny.npz"), **out)
+    print("clap_text_tiny.npz", {k: v.shape for k, v in out.items() if not k.startswith("w::")})
+
+
 if __name__ == "__main__":
-    vocoder()
-    ddim()
-    poly()
+    which = sys.argv[1:] or ["vocoder", "ddim", "poly", "clap_text"]
+    for name in which:
+        globals()[name]()

@@ -1,0 +1,68 @@
+"""GPU: the training driver end to end on the reference's collate_fn batch contract:
+mel -> VAE encode -> latents, token ids -> CLAP tower -> prompt embeddings, LoRA step, peft-keyed checkpoint that the
+inference driver's loading sequence [REF script/inference/generate_audio.py:18-36] accepts."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_script_mel_contract_and_checkpoint_roundtrip(tmp_path):
+    from safetensors.torch import load_file
+    from audioldm_with_lora_amd import configs
+    from audioldm_with_lora_amd.lora import (LoraConfig, convert_state_dict_to_diffusers, get_peft_model,
+                                             get_peft_model_state_dict)
+    from audioldm_with_lora_amd.script import train
+    from audioldm_with_lora_amd.unet import UNet2DConditionModel
+    out = str(tmp_path / "lora")
+    loss = train.main(["--tiny", "--input", "mel", "--max-train-steps", "5", "--train-batch-size", "2", "--rank", "2",
+                       "--lora-alpha", "2", "--target-modules", "to_q,to_v", "--output-dir", out, "--learning-rate", "1e-3"])
+    assert loss == loss and 0.0 < loss < 10.0                                  # finite epsilon-MSE
+    f = os.path.join(out, "checkpoint-5", "model.safetensors")
+    sd = load_file(f)
+    assert len(sd) == 64 * 2                                                   # 64 (q, v) pairs: lora_A + lora_B
+    assert all(k.startswith("base_model.model.") and ".default.weight" in k for k in sd)
+    assert any(float(v.abs().max()) > 0 for k, v in sd.items() if "lora_B" in k)   # B left its zero init: training happened
+    # the reference's inference-side loading sequence
+    torch.manual_seed(1234)
+    unet = UNet2DConditionModel(**configs.tiny_unet())
+    unet_lora = get_peft_model(unet, LoraConfig(r=2, lora_alpha=2, target_modules=["to_q", "to_v"], init_lora_weights="gaussian"))
+    res = unet_lora.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    got = get_peft_model_state_dict(unet_lora)
+    assert len(got) == 128
+    for k, v in got.items():
+        kk = k.replace(".weight", ".default.weight")
+        torch.testing.assert_close(v.cpu(), sd[kk])
+    diff = convert_state_dict_to_diffusers(got)
+    assert all((".lora.down.weight" in k) or (".lora.up.weight" in k) for k in diff)
+
+
+def test_encode_batch_matches_oracle():
+    """[REF train:495-524] on the HIP kernels vs the same lines on the CPU oracle (mode() instead of sample() so no RNG)."""
+    import torch.nn.functional as F
+    from audioldm_with_lora_amd import configs
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.script.train import synthetic_batch
+    from audioldm_with_lora_amd.vae import AutoencoderKL
+    from oracle.clap_text import ClapTextModelWithProjection as OClap
+    from oracle.vae import AutoencoderKL as OVae
+    torch.manual_seed(5)
+    ovae, oclap = OVae(**configs.tiny_vae()).eval(), OClap(**dict(configs.tiny_clap_text(), max_position_embeddings=514)).eval()
+    vae, clap = AutoencoderKL(**configs.tiny_vae()), ClapTextModelWithProjection(**dict(configs.tiny_clap_text(), max_position_embeddings=514))
+    vae.load_state_dict(ovae.state_dict())
+    clap.load_state_dict(oclap.state_dict())
+    vae, clap = vae.cuda(), clap.cuda()
+    batch = synthetic_batch(2, torch.Generator().manual_seed(0), vocab=200)
+    batch["log_mel_spec"] = batch["log_mel_spec"][:, :, :64]                     # 64 frames keep the CPU side quick
+    with torch.no_grad():
+        want_lat = ovae.encode(batch["log_mel_spec"]).latent_dist.mode() * ovae.config.scaling_factor
+        want_emb = F.normalize(oclap(batch["input_ids"].squeeze(1), batch["attention_mask"].squeeze(1)).text_embeds, dim=-1)
+    got_lat = vae.encode(batch["log_mel_spec"].cuda()).latent_dist.mode() * vae.config.scaling_factor
+    got_emb = F.normalize(clap(input_ids=batch["input_ids"].squeeze(1), attention_mask=batch["attention_mask"].squeeze(1)).text_embeds, dim=-1)
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert got_lat.shape == want_lat.shape == (2, 8, 16, 16)
+    assert rel(got_lat, want_lat) < 3e-2
+    assert rel(got_emb, want_emb) < 3e-2
