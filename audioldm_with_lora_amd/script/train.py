@@ -36,10 +36,15 @@ from ..unet import UNet2DConditionModel
 from ..vae import AutoencoderKL
 
 
-def encode_batch(vae, text_encoder, batch, generator=None):
-    """collate_fn batch -> (latents [B,8,H/4,16], prompt_embeds [B,512]) exactly as [REF train:495-524]."""
+def encode_batch(vae, text_encoder, batch, generator=None, mel_frontend=None):
+    """collate_fn batch -> (latents [B,8,H/4,16], prompt_embeds [B,512]) exactly as [REF train:495-524].  A batch that
+    carries `waveform` [B,1,T] instead of `log_mel_spec` goes through the GPU log-mel front end first (mel.py)."""
     dev = vae.post_quant_conv.weight.device
-    latents = vae.encode(batch["log_mel_spec"].to(dev, torch.float32)).latent_dist.sample(generator) * vae.config.scaling_factor
+    if "log_mel_spec" in batch:
+        mel = batch["log_mel_spec"].to(dev, torch.float32)
+    else:
+        mel = mel_frontend(batch["waveform"].to(dev, torch.float32).flatten(1))
+    latents = vae.encode(mel).latent_dist.sample(generator) * vae.config.scaling_factor
     input_ids = batch["input_ids"].squeeze(1)
     attention_mask = batch["attention_mask"].squeeze(1)
     text_embeds = text_encoder(input_ids=input_ids, attention_mask=attention_mask, return_dict=True).text_embeds

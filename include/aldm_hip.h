@@ -215,6 +215,16 @@ int aldm_mse_grad(const float* pred, const float* target, long long n, float gra
 int aldm_adamw_flat(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Log-mel front end: the dataloader's mel_spectrogram_train + pad_spec
+ * [REF script/data/datasets.py:301-354,385-398] as one kernel.  wav fp32 [B][T] in [-1, 1];
+ * reflect padding (n_fft - hop)/2, n_fft-point STFT (n_fft must be 1024) with `window`[n_fft],
+ * magnitude, mel_basis fp32 [n_mels][n_fft/2+1] with non-zero bin ranges mel_range int32 [n_mels][2],
+ * log(max(., clamp_min)); out fp32 [B][target_frames][n_mels], frames past the clip are zeros.
+ * ------------------------------------------------------------------------------------------ */
+int aldm_log_mel(const float* wav, int B, int T, int n_fft, int hop, const float* window, const float* mel_basis,
+                 const int* mel_range, int n_mels, int target_frames, float clamp_min, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
