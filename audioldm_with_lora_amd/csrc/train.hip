@@ -311,6 +311,98 @@ __global__ __launch_bounds__(256) void tn_small_kernel(const bf16* __restrict__ 
   }
 }
 
+// MFMA form of the same product for the aligned case (ldq, Qc multiples of 8): out[p][q] = sum_m P[m][p] Q[m][q] reduces over
+// the ROW index of two row-major matrices, so both MFMA operands are k-strided in memory.  Tiles are staged row-major in LDS
+// as [32 m][32 col] slabs with 64-byte rows and consumed through gfx950's transposing LDS read (ds_read_b64_tr_b16: each
+// 16-lane group fetches 4 rows x 16 columns and receives them column-major), which is conflict-free on 64-byte rows (a
+// 32-lane half reads 4 x 64 contiguous bytes).  A workgroup owns 128 q-columns (one 32-column slab per wave) and an m-range;
+// partial sums leave through the same fp32 atomics / row table as the scalar kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const char* slab, int lane, int kbase) {
+  // 32x32x16 operand for row/column (lane & 31): k = kbase + 8*(lane>>5) .. +7
+  const int g = lane >> 4, qrow = (lane >> 2) & 3, pp = lane & 3;
+  const char* a = slab + (kbase + 8 * (g >> 1) + qrow) * 64 + (16 * (g & 1) + 4 * pp) * 2;
+  typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * 64));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int RP>
+__global__ __launch_bounds__(256) void tn_mfma_kernel(const bf16* __restrict__ P, const bf16* __restrict__ Q, int M, int ldq,
+                                                      int Qc, const TnRow* __restrict__ rows, int m_per_block) {
+  constexpr int PT = RP / 32;                    // 32-row p tiles
+  constexpr int SLAB = 32 * 64;                  // bytes of one [32 m][32 col] bf16 slab
+  constexpr int STAGE = (PT + 4) * SLAB;
+  constexpr int PCH = PT * 128;                  // 16-byte chunks of the P tile per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.x * 128;
+  const int mb = blockIdx.y * m_per_block, me = min(M, mb + m_per_block);
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 qreg[2], preg;
+  auto prefetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, ch = idx & 15;
+      const int m = m0 + row, q = q0 + ch * 8;
+      qreg[i] = (m < me && q < Qc) ? *reinterpret_cast<const bf16x8*>(Q + (long long)m * ldq + q) : zero8;
+    }
+    if (tid < PCH) {
+      const int row = tid / (PT * 4), ch = tid - row * (PT * 4);
+      preg = (m0 + row < me) ? *reinterpret_cast<const bf16x8*>(P + (long long)(m0 + row) * RP + ch * 8) : zero8;
+    }
+  };
+  auto stage = [&](int buf) {
+    char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, ch = idx & 15;
+      *reinterpret_cast<bf16x8*>(st + (PT + (ch >> 2)) * SLAB + row * 64 + (ch & 3) * 16) = qreg[i];
+    }
+    if (tid < PCH) {
+      const int row = tid / (PT * 4), ch = tid - row * (PT * 4);
+      *reinterpret_cast<bf16x8*>(st + (ch >> 2) * SLAB + row * 64 + (ch & 3) * 16) = preg;
+    }
+  };
+  f32x16 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int nst = (me - mb + 31) / 32;
+  prefetch(mb);
+  stage(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    if (s + 1 < nst) prefetch(mb + 32 * (s + 1));
+    const char* st = smem + (s & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 bq = tr_frag(st + (PT + wave) * SLAB, lane, 16 * ks);
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const bf16x8 ap = tr_frag(st + t * SLAB, lane, 16 * ks);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bq, acc[t], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nst) stage((s + 1) & 1);
+    __syncthreads();
+  }
+  const int q = q0 + wave * 32 + (lane & 31), hh = lane >> 5;
+  if (q < Qc) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const TnRow r = rows[t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
+        if (r.dst && q >= r.qlo && q < r.qhi) atomicAdd(r.dst + (long long)(q - r.qlo) * r.qstride, acc[t][i] * r.scale);
+      }
+  }
+}
+
 struct PackJob { const float* src; bf16* dst; int rows, cols, src_ld, dst_ld, transpose; float scale; };
 __global__ void lora_pack_kernel(const PackJob* __restrict__ jobs) {
   const PackJob j = jobs[blockIdx.x];
@@ -415,6 +507,20 @@ extern "C" int aldm_upsample_nearest_bwd(const void* dy, int B, int IH, int IW, 
 
 extern "C" int aldm_tn_small(const void* P, int Rp, const void* Q, int ldq, int Qc, int M, const void* rows_dev, void* stream) {
   ALDM_CHECK_ARG(P && Q && rows_dev && M > 0 && Qc > 0 && (Rp == 32 || Rp == 64), "tn_small: bad args");
+  if (ldq % 8 == 0 && Qc % 8 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0) {
+    // MFMA path: 128 q-columns per workgroup, the m-range cut so that ~256 workgroups run (64-row granules)
+    const int qt = cdiv(Qc, 128);
+    int msplit = 256 / qt;
+    if (msplit < 1) msplit = 1;
+    int mpb = cdiv(cdiv(M, msplit), 32) * 32;
+    if (mpb < 64) mpb = 64;
+    dim3 grid(qt, cdiv(M, mpb));
+    if (Rp == 32)
+      hipLaunchKernelGGL(tn_mfma_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)P, (const bf16*)Q, M, ldq, Qc, (const TnRow*)rows_dev, mpb);
+    else
+      hipLaunchKernelGGL(tn_mfma_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)P, (const bf16*)Q, M, ldq, Qc, (const TnRow*)rows_dev, mpb);
+    return aldm_launch_status("tn_small");
+  }
   const int qt = cdiv(Qc, 64);
   int msplit = 512 / qt;
   if (msplit < 1) msplit = 1;

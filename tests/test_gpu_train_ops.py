@@ -158,3 +158,39 @@ def test_tn_small_lora_pack_mse(ops):
     dp = ops.mse_grad(pred.to(DEV), tgt.to(DEV), loss)
     assert abs(float(loss) - float(F.mse_loss(pred, tgt))) < 1e-5
     close(dp, 2 * (pred - tgt) / pred.numel(), rtol=1e-2, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,Rp,Qc,ldq", [(8192, 32, 768, 768), (2048, 64, 384, 1152), (515, 32, 136, 136), (64, 64, 1920, 1920),
+                                         (300, 32, 100, 100), (97, 32, 36, 44)])
+def test_tn_small_mfma_and_scalar_paths(ops, M, Rp, Qc, ldq):
+    """out[p][q] = sum_m P[m][p] Q[m][q] through the row table: aligned shapes take the MFMA / transposing-LDS-read kernel,
+    ldq or Qc not a multiple of 8 the scalar one; windows (qlo, qhi), transposed scatter and scaling as the trainer uses."""
+    import struct
+    g = torch.Generator().manual_seed(M + Qc)
+    P = bf(torch.randn(M, Rp, generator=g))
+    Qfull = bf(torch.randn(M, ldq, generator=g))
+    want = P.t() @ Qfull[:, :Qc]                            # [Rp][Qc]
+    half = (Qc // 2) // 4 * 4
+    flat = torch.zeros(Rp * Qc + 16, device=DEV)
+    rows = torch.zeros(Rp, 24, dtype=torch.uint8)
+    base = flat.data_ptr()
+    nrows = Rp - 3                                          # the last rank rows are padding (dst = NULL)
+    for p_ in range(nrows):
+        if p_ % 2 == 0:                                     # dense row, full window
+            rec = struct.pack("<qiiif", base + 4 * p_ * Qc, 0, Qc, 1, 1.0)
+        else:                                               # upper half window only, scaled
+            rec = struct.pack("<qiiif", base + 4 * p_ * Qc, half, Qc, 1, 0.5)
+        rows[p_] = torch.tensor(list(rec), dtype=torch.uint8)
+    Qd = Qfull.to(torch.bfloat16).to(DEV)
+    ops.tn_small(P.to(torch.bfloat16).to(DEV), Qd, rows.to(DEV), Qc=Qc)
+    got = flat.cpu()[:Rp * Qc].view(Rp, Qc)
+    tol = 2e-3 * float(want.abs().max())
+    for p_ in range(Rp):
+        if p_ >= nrows:
+            assert float(got[p_].abs().max()) == 0.0
+        elif p_ % 2 == 0:
+            close(got[p_], want[p_], rtol=1e-3, atol=tol)
+        else:
+            close(got[p_, :Qc - half], 0.5 * want[p_, half:], rtol=1e-3, atol=tol)
+            assert float(got[p_, Qc - half:].abs().max()) == 0.0
+    assert float(flat[Rp * Qc:].abs().max()) == 0.0        # nothing written past the table's windows
