@@ -35,7 +35,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
                                                                    const bf16* __restrict__ dy, int HW, int C1, int C2,
                                                                    int groups, float eps, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
-                                                                   bf16* __restrict__ dx, bf16* __restrict__ dx2) {
+                                                                   bf16* __restrict__ dx, bf16* __restrict__ dx2, int accumulate) {
   __shared__ float red[16];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -120,8 +120,16 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
         }
         o[k] = (bf16)(rstd * (dz * gamma[c + k] - s1 - xh * s2));
       }
-      if (c < C1) *reinterpret_cast<bf16x4*>(dx + ((long long)b * HW + pix) * C1 + c) = o;
-      else if (dx2) *reinterpret_cast<bf16x4*>(dx2 + ((long long)b * HW + pix) * C2 + (c - C1)) = o;
+      // accumulate bit 0 / 1: dx / dx2 already hold a gradient from another consumer of x / x2 -- add to it in place
+      if (c < C1) {
+        bf16x4* dst = reinterpret_cast<bf16x4*>(dx + ((long long)b * HW + pix) * C1 + c);
+        if (accumulate & 1) { const bf16x4 a = *dst; for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
+        *dst = o;
+      } else if (dx2) {
+        bf16x4* dst = reinterpret_cast<bf16x4*>(dx2 + ((long long)b * HW + pix) * C2 + (c - C1));
+        if (accumulate & 2) { const bf16x4 a = *dst; for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
+        *dst = o;
+      }
     }
   }
 }
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
 constexpr int LN_MAXC = 4;
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int M,
                                                             int C, const float* __restrict__ gamma, float eps,
-                                                            bf16* __restrict__ dx) {
+                                                            bf16* __restrict__ dx, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -183,6 +191,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
       for (int k = 0; k < 8; ++k) {
         const float xh = ((float)v[i][k] - mean) * rstd;
         r[k] = (bf16)(rstd * ((float)d[i][k] * gamma[ch * 8 + k] - s1 - xh * s2));
+      }
+      if (accumulate) {                        // dx already holds the residual stream's gradient: add in place
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + ch * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = (bf16)((float)r[k] + (float)a[k]);
       }
       *reinterpret_cast<bf16x8*>(o + ch * 8) = r;
     }
@@ -454,7 +467,7 @@ inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / p
 
 extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
                                   float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2,
-                                  void* stream) {
+                                  int accumulate, void* stream) {
   ALDM_CHECK_ARG(x && dy && dx && gamma && beta && B > 0 && HW > 0, "groupnorm_bwd: bad args");
   const int C = C1 + C2;
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0 && (C2 == 0 || x2), "groupnorm_bwd: bad channels");
@@ -463,7 +476,7 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
 #define ALDM_GNB(QPT)                                                                                                  \
   hipLaunchKernelGGL(groupnorm_bwd_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
                      (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
-                     (bf16*)dx, (bf16*)dx2)
+                     (bf16*)dx, (bf16*)dx2, accumulate)
   if (nquads <= 4 * GN_THREADS) ALDM_GNB(4);
   else if (nquads <= 8 * GN_THREADS) ALDM_GNB(8);
   else if (nquads <= 16 * GN_THREADS) ALDM_GNB(16);
@@ -473,10 +486,10 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
 }
 
 extern "C" int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx,
-                                  void* stream) {
+                                  int accumulate, void* stream) {
   ALDM_CHECK_ARG(x && dy && dx && gamma && M > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "layernorm_bwd: bad args");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                     (const bf16*)dy, M, C, gamma, eps, (bf16*)dx);
+                     (const bf16*)dy, M, C, gamma, eps, (bf16*)dx, accumulate);
   return aldm_launch_status("layernorm_bwd");
 }
 

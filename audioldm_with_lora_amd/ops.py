@@ -473,20 +473,31 @@ def attention_bwd(qkv, qkvT, dO, O, lse, B, N, H, d):
     return dqkv
 
 
-def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True):
+def _into(buf, like):
+    assert buf.is_contiguous() and buf.numel() == like.numel() and buf.dtype == like.dtype
+    return buf
+
+
+def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True, dx_into=None, dx2_into=None):
+    """dx (dx2) of act(group_norm(cat[x, x2])).  dx_into / dx2_into: existing gradient buffers to ADD into in place
+    (the tensor has other consumers); the returned tensors are then those buffers."""
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    dx = torch.empty_like(x)
-    dx2 = torch.empty_like(x2) if (x2 is not None and need_dx2) else None
+    dx = torch.empty_like(x) if dx_into is None else _into(dx_into, x)
+    dx2 = None
+    if x2 is not None and need_dx2:
+        dx2 = torch.empty_like(x2) if dx2_into is None else _into(dx2_into, x2)
+    accumulate = (1 if dx_into is not None else 0) | (2 if (dx2 is not None and dx2_into is not None) else 0)
     check(_lib.load().aldm_groupnorm_bwd(_p(x), _p(x2), _p(dy), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act,
-                                         _p(dx), _p(dx2), _stream()), "aldm_groupnorm_bwd")
+                                         _p(dx), _p(dx2), accumulate, _stream()), "aldm_groupnorm_bwd")
     return dx, dx2
 
 
-def layernorm_bwd(x2d, dy, gamma, eps=1e-5):
+def layernorm_bwd(x2d, dy, gamma, eps=1e-5, dx_into=None):
     M, Cc = x2d.shape
-    dx = torch.empty_like(x2d)
-    check(_lib.load().aldm_layernorm_bwd(_p(x2d), _p(dy), M, Cc, _p(gamma), eps, _p(dx), _stream()), "aldm_layernorm_bwd")
+    dx = torch.empty_like(x2d) if dx_into is None else _into(dx_into, x2d)
+    check(_lib.load().aldm_layernorm_bwd(_p(x2d), _p(dy), M, Cc, _p(gamma), eps, _p(dx), int(dx_into is not None), _stream()),
+          "aldm_layernorm_bwd")
     return dx
 
 

@@ -51,6 +51,22 @@ def acc(v, g):
     v.g = g if v.g is None else ops.add_bf16(v.g, g.reshape(v.g.shape))
 
 
+def prior(v, like=None):
+    """The gradient v already holds from its other consumers (residual / skip joins), shaped like `like`, or None.
+    Kernels that can ADD it (GEMM epilogue `res=`, norm backward `dx_into=`) take it instead of a separate add launch.
+    In-place accumulation is safe: v.g may alias a downstream tensor's gradient, but every reader of that tensor has
+    already run by the time an upstream op's backward executes (the tape runs in reverse)."""
+    if v is None or not v.rg or v.g is None:
+        return None
+    return v.g if like is None else v.g.view(like.shape)
+
+
+def put(v, g):
+    """Store a gradient that already includes prior(v)."""
+    if v is not None and v.rg:
+        v.g = g
+
+
 class Tape:
     def __init__(self):
         self.fns = []
@@ -103,13 +119,12 @@ def t_conv(tape, x, pw, x2=None, stride=(1, 1), pad=(0, 0), up_size=None, rowbia
                 continue
             bw = _bwd_pack(pw, lo, hi)
             ih, iw = src.t.shape[1], src.t.shape[2]
-            if stride == (2, 2):
-                dx = ops.conv(dy, bw, pad=bpad, in_dilate=2, out_hw=(ih, iw))
-            elif up_size is not None:
-                dx = ops.upsample_nearest_bwd(ops.conv(dy, bw, pad=bpad), ih, iw)
+            if up_size is not None:
+                acc(src, ops.upsample_nearest_bwd(ops.conv(dy, bw, pad=bpad), ih, iw))
+            elif stride == (2, 2):
+                put(src, ops.conv(dy, bw, pad=bpad, in_dilate=2, out_hw=(ih, iw), res=prior(src, src.t)))
             else:
-                dx = ops.conv(dy, bw, pad=bpad)
-            acc(src, dx)
+                put(src, ops.conv(dy, bw, pad=bpad, res=prior(src, src.t)))
     tape.record(bwd)
     return y
 
@@ -122,9 +137,9 @@ def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None):
             if y.g is None:
                 return
             dx, dx2 = ops.groupnorm_bwd(x.t, y.g, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None),
-                                        need_dx2=(x2 is not None and x2.rg))
-            acc(x, dx)
-            acc(x2, dx2)
+                                        need_dx2=(x2 is not None and x2.rg), dx_into=prior(x), dx2_into=prior(x2))
+            put(x, dx)
+            put(x2, dx2)
         tape.record(bwd)
     return y
 
@@ -132,7 +147,7 @@ def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None):
 def t_layernorm(tape, x, gamma, beta):
     y = Var(ops.layernorm(x.t, gamma, beta), x.rg)
     if x.rg:
-        tape.record(lambda: acc(x, ops.layernorm_bwd(x.t, y.g, gamma)) if y.g is not None else None)
+        tape.record(lambda: put(x, ops.layernorm_bwd(x.t, y.g, gamma, dx_into=prior(x))) if y.g is not None else None)
     return y
 
 
@@ -193,8 +208,8 @@ def t_lora_linear(tape, x, site, res=None):
             return
         acc(res, dy)
         U = torch.empty(M, site.Rp, dtype=torch.bfloat16, device=dy.device)
-        dx = ops.linear(dy, site.bwd, lora_t_out=U, splits=1)     # dx = dy W + (dy sB) A ; U = dy sB
-        acc(x, dx)
+        g0 = prior(x, x.t)
+        put(x, ops.linear(dy, site.bwd, lora_t_out=U, splits=1, res=g0))     # dx = dy W + (dy sB) A (+ prior) ; U = dy sB
         ops.tn_small(T, dy, site.rows_db, Qc=site.N)
         ops.tn_small(U, x.t, site.rows_da, Qc=site.K)
     tape.record(bwd)

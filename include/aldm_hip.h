@@ -188,9 +188,14 @@ int aldm_add_noise(const float* x, const float* noise, const float* coef, int B,
  * is frozen, so only dX flows through GroupNorm / LayerNorm / GEGLU / up-sampling, and only the LoRA matrices get
  * weight gradients (aldm_tn_small).  dX of convolutions / linears is aldm_igemm with transposed weights.
  * ------------------------------------------------------------------------------------------ */
+/* `accumulate`: the tensor x (x2) feeds more than one consumer (residual / skip connections), so its gradient buffer may
+   already hold the other consumers' share: bit 0 (bit 1) makes the kernel ADD into dx (dx2) in place instead of
+   overwriting it -- the separate element-wise add launch per residual join disappears. */
 int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
-                       float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2, void* stream);
-int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx, void* stream);
+                       float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2, int accumulate,
+                       void* stream);
+int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx, int accumulate,
+                       void* stream);
 /* GEGLU on the interleaved (16 value | 16 gate) projection h [M][2I]: out [M][I] = value * gelu(gate), and its backward */
 int aldm_geglu_fwd(const void* h, long long M, int I, void* out, void* stream);
 int aldm_geglu_bwd(const void* h, const void* dout, long long M, int I, void* dh, void* stream);

@@ -52,6 +52,16 @@ def test_groupnorm_bwd(ops, B, HW, C1, C2, groups, act):
     close(nchw(dx), x.grad[:, :C1])
     if C2:
         close(nchw(dx2), x.grad[:, C1:])
+    # in-place accumulation into gradients the tensors already hold (residual / skip joins)
+    p1 = bf(torch.randn(B, C1, H, W, generator=g))
+    p2 = bf(torch.randn(B, C2, H, W, generator=g)) if C2 else None
+    b1, b2 = nhwc(p1), (nhwc(p2) if C2 else None)
+    r1, r2 = ops.groupnorm_bwd(x1, nhwc(dy), gm.to(DEV), bt.to(DEV), groups, 1e-5, act, x2=x2, dx_into=b1, dx2_into=b2)
+    assert r1.data_ptr() == b1.data_ptr()
+    close(nchw(r1), x.grad[:, :C1] + p1)
+    if C2:
+        assert r2.data_ptr() == b2.data_ptr()
+        close(nchw(r2), x.grad[:, C1:] + p2)
 
 
 def test_layernorm_and_geglu_bwd(ops):
@@ -63,6 +73,11 @@ def test_layernorm_and_geglu_bwd(ops):
         F.layer_norm(x, (Cc,), gm, bt, 1e-5).backward(dy)
         dx = ops.layernorm_bwd(x.detach().to(torch.bfloat16).to(DEV), dy.to(torch.bfloat16).to(DEV), gm.to(DEV))
         close(dx, x.grad)
+        prev = bf(torch.randn(50, Cc, generator=g))
+        buf = prev.to(torch.bfloat16).to(DEV)
+        out = ops.layernorm_bwd(x.detach().to(torch.bfloat16).to(DEV), dy.to(torch.bfloat16).to(DEV), gm.to(DEV), dx_into=buf)
+        assert out.data_ptr() == buf.data_ptr()
+        close(out, x.grad + prev)
     # GEGLU on the interleaved layout
     M, I = 40, 64
     h = bf(torch.randn(M, 2 * I, generator=g)).requires_grad_()
@@ -124,7 +139,7 @@ def test_attention_fwd_lse_and_bwd(ops, B, N, H, d):
     out, lse = ops.attention_train(dev, qkvT, B, N, H, d)
     close(out, o.detach(), rtol=2e-2, atol=1e-2)
     s = (sp(q) @ sp(k).transpose(-1, -2)).detach() / math.sqrt(d)
-    close(lse, torch.logsumexp(s, -1) * 1.4426950408889634, rtol=1e-2, atol=3e-2)
+    close(lse, torch.logsumexp(s, -1) * 1.4426950408889634, rtol=1e-2)
     dqkv = ops.attention_bwd(dev, qkvT, dO.to(torch.bfloat16).to(DEV), out, lse, B, N, H, d)
     close(dqkv, qkv.grad, rtol=3e-2)
 
