@@ -169,6 +169,22 @@ def pick_tile(M, N):
     return _lib.TILE_64x64
 
 
+def pick_ring(tile, bm, bn, rp, nwg, ktiles):
+    """LDS-DMA ring depth (2..4 K-tiles in flight).  Rule from tools/bench_igemm.py --ring sweeps on MI355X:
+    residency first -- the ring must leave room for ceil(nwg / 256 CUs) workgroups per CU inside the 160 KiB of LDS,
+    otherwise the grid runs in two rounds (128x64 tile, 500 workgroups: ring 4 = 98 KiB/WG -> 38.9 us, ring 3 -> 23.9 us);
+    then depth -- few workgroups (low-resolution levels) have nothing else to hide the weight stream's latency behind, so
+    they take the deepest ring that fits; big grids gain nothing past 2-3."""
+    if tile == 6:
+        return 2
+    stage = (bm + bn + rp) * 128
+    extra = (bn * 128 if rp else 0) + 2 * bm * 4
+    per_cu = min(8, max(1, math.ceil(nwg / 256)))
+    fit = ((160 * 1024) // per_cu - extra) // stage
+    want = 4 if nwg <= 512 else (2 if ktiles <= 24 else 3)
+    return max(2, min(want, fit))
+
+
 TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event).
@@ -281,9 +297,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if not ring:
         bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128)}[tile]
         nwg = math.ceil(M / bm) * math.ceil(pw.N / bn) * max(1, splits)
-        # few workgroups (low-resolution levels): nothing else hides the HBM latency of the weight stream -> deepest ring;
-        # many workgroups: occupancy matters more than depth (tools/bench_igemm.py sweeps)
-        ring = 2 if tile == 6 else (4 if nwg <= 512 else (2 if ktiles <= 24 else 3))
+        ring = pick_ring(tile, bm, bn, pw.Rp, nwg, ktiles)
     a.ring = ring
     ktot = KH * KW * pw.Cin
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)

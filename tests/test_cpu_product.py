@@ -138,6 +138,8 @@ def test_packing_layouts():
     assert float(lin.lora_b[0, 0]) == 2.0 and float(lin.lora_b[0, 4]) == 0.0 and float(lin.lora_b[16, 4]) == 1.0
     assert ops.pick_tile(32000, 128) == 3 and ops.pick_tile(512, 640) == 2 and ops.pick_tile(32000, 256) == 6
     assert ops.auto_splits(512, 640, 90) == 4 and ops.auto_splits(32000, 128, 18) == 1
+    # ring depth: 500 workgroups of the 128x64 tile must stay 2-per-CU resident (3 stages), 80x4 split-K ones take the deepest ring
+    assert ops.pick_ring(3, 128, 64, 0, 500, 18) == 3 and ops.pick_ring(2, 64, 64, 0, 320, 90) == 4 and ops.pick_ring(2, 64, 64, 32, 1500, 4) == 2
 
 
 def test_vocoder_transposed_conv_phase_decomposition_matches_torch():
