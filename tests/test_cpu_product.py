@@ -169,3 +169,18 @@ def test_vocoder_transposed_conv_phase_decomposition_matches_torch():
                         acc += w[:, :, j].t() @ x[0, :, s]
                 got[0, :, t0 + u * qi] = acc
         torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_tuned_table_is_well_formed():
+    """tuned_gfx950.json (tools/autotune.py): every entry is a launchable (tile, ring, splits) triple."""
+    import json
+    import os
+    from audioldm_with_lora_amd import ops
+    assert os.path.exists(ops.TUNED_PATH)
+    table = json.load(open(ops.TUNED_PATH))["igemm"]
+    assert table, "empty table"
+    for key, (tile, ring, splits) in table.items():
+        assert key.startswith("M") and tile in ops.TILE_DIMS and 2 <= ring <= 4 and 1 <= splits <= 16, (key, tile, ring, splits)
+        if " vt1 " in key or " ln1 " in key:
+            assert splits == 1
+    assert ops.TUNED == {k: tuple(v) for k, v in table.items()} or os.environ.get("ALDM_NO_TUNED") == "1"
