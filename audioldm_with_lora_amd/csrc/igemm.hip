@@ -10,6 +10,7 @@ int aldm_launch_tile_128x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStr
 int aldm_launch_tile_64x128(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_64x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_128x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_halo(const IgemmDev& d, int tile, int ring, hipStream_t st);
 
 static int pick_tile(int M, int N) {
   auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
@@ -78,7 +79,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.w_bytes = (unsigned)wb;
     d.la_bytes = (unsigned)lb;
     d.lb_bytes = (unsigned)(2ull * p->Cout * p->Rp);
-    d.fd_ohw = make_fastdiv((unsigned)d.OHW); d.fd_ow = make_fastdiv((unsigned)d.OW);
+    d.fd_ohw = make_fastdiv((unsigned)d.OHW); d.fd_ow = make_fastdiv((unsigned)d.OW); d.fd_halo = make_fastdiv((unsigned)d.OW + 2u);
     d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
 #ifdef ALDM_DIAG
     d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer
@@ -97,6 +98,11 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_64x128: rc = aldm_launch_tile_64x128(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_64x64: rc = aldm_launch_tile_64x64(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_HALO_128x128:
+    case ALDM_TILE_HALO_64x128:
+      if (p->Rp || vt) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T"); return ALDM_E_UNSUPPORTED; }
+      rc = aldm_launch_halo(d, tile, p->ring, st);
+      break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;
   }
   if (rc != ALDM_OK) return rc;

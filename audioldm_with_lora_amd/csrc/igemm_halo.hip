@@ -1,0 +1,237 @@
+// 3x3 / stride-1 / pad-1 convolution with an LDS-resident input HALO tile (gfx950).
+//
+// Why: the generic implicit-GEMM kernel (igemm_core.h) re-gathers the activation tile once per filter tap, so a 3x3 conv
+// pulls every input pixel through the CU's texture path 9 x (N / BN) times.  Measured on MI355X that path -- not the MFMA
+// pipe, not HBM -- bounds those kernels (tools/diag_igemm.py: ~55 % of the main loop is LDS-DMA issue; 221 MB of L2->LDS
+// traffic for the 9.4 GFLOP level-0 conv).  Here a workgroup owns BM/W whole image rows of ONE image and keeps, per
+// 64-channel chunk, the (BM/W + 2) x (W + 2) halo of input pixels in LDS; the nine taps read it at nine row offsets, so
+// the activation is fetched ONCE per chunk and only the weight tiles stream (S-deep LDS-DMA ring, counted vmcnt, one raw
+// barrier per tap) -- 2.6x fewer bytes through the texture path at level 0.
+// Measured (MI355X, in a replayed graph, level-0 conv 128->128 on 8 x 250 x 16): 21.0 us per launch = 2.5 launch floor
+// + 3.3 tap-loop skeleton (waits / barriers) + 9.3 DMA + MFMA + 5.8 epilogue; the generic 128x64 tile takes 24 us.  The
+// in-context tuner (tools/autotune.py) picks this kernel where it wins (the 256..384-wide level-0 / training convs).
+//
+//   * 8 wave64s; v_mfma_f32_16x16x32_bf16, issued "swapped" like the generic kernel so that the shared epilogue
+//     (bias / time-embedding row bias / residual / activation / bf16 or fp32 store) applies unchanged.
+//   * halo image = [halo pixel][64 ch] rows of 128 B with the same XOR swizzle as the generic A tile; zero padding and
+//     rows past the image come from the buffer descriptor's range check (voffset 0x80000000 -> the DMA writes zeros).
+//   * virtual concat (x | x2) and the folded nearest 2x up-sampling are applied in the halo gather.
+//
+// Serves ResnetBlock2D conv1 / conv2 and the up-sampler convs of UNet2DConditionModel.forward
+// [REF script/train/train_audioldm_lora.py:539-546], their dX in the LoRA trainer, and the same blocks of AutoencoderKL.
+#include "igemm_core.h"
+
+namespace aldm_igemm_detail {
+
+template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S>
+__global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int NT = 512, RPP = NT / 8;                 // 64 tile rows per whole-workgroup DMA pass
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int W_PASSES = BN / RPP;                    // weight-tile DMA instructions per thread per tap
+  constexpr int D = S - 1;                              // taps in flight ahead of the MFMAs
+  constexpr int HALO_BYTES = HP * RPP * 128;
+  constexpr int BSTAGE = BN * 128;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(BN % RPP == 0, "weight tile rows must be whole DMA passes");
+  static_assert((D - 1) * W_PASSES + HP < 64, "vmcnt immediate");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][halo: HP*64 x 128 B] [S][B: BN x 128 B]
+  char* const Hs = smem;
+  char* const Bring = smem + 2 * HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int W = p.OW, H = p.OH;                         // output == (virtual) input extent for stride 1 / pad 1
+  const int HW2 = W + 2;
+  const int rows_pt = BM / W;                           // image rows per tile (host guarantees BM % W == 0)
+  const int tpi = (H + rows_pt - 1) / rows_pt;          // tiles per image
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int img = tile_m / tpi, ty0 = (tile_m - img * tpi) * rows_pt;
+  const int m0 = img * p.OHW + ty0 * W, n0 = tile_n * BN;
+  const int halo_rows = (rows_pt + 2) * HW2;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? (const void*)p.x2 : (const void*)p.x, p.x2 ? p.x2_bytes : p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+
+  const int rbase = tid >> 3;
+  const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);    // logical (source) chunk landing in this lane's physical slot
+  // halo gather: pixel index (in source pixels) of this thread's row in each pass, or -1 (zero row)
+  int h_pix[HP];
+  {
+    const FastDiv fd_w2 = {p.fd_halo.mul, p.fd_halo.shift};
+    const bool up = p.UH > 0;
+#pragma unroll
+    for (int ps = 0; ps < HP; ++ps) {
+      const int hp = rbase + RPP * ps;
+      const int hy = fdiv(hp, fd_w2), hx = hp - hy * HW2;
+      const int gy = ty0 - 1 + hy, gx = hx - 1;
+      const bool ok = hp < halo_rows && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const int sy = up ? (gy >> 1) : gy, sx = up ? (gx >> 1) : gx;
+      h_pix[ps] = ok ? (img * p.IH + sy) * p.IW + sx : -1;
+    }
+  }
+  unsigned b_off[W_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < W_PASSES; ++ps) {
+    const int row = min(n0 + rbase + RPP * ps, p.N - 1);
+    b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
+  }
+
+  const int nchunks = p.Ctot >> 6;
+  const int nitems = nchunks * 9;
+  // item cursor of the ISSUE side (scalar): chunk, tap
+  int i_c = 0, i_tap = 0;
+  auto issue = [&](int item, int stage) {
+    const bool live = item < nitems;
+    char* bdst = Bring + stage * BSTAGE + wave * 1024;
+    if (live && i_tap == 0) {                            // first tap of a chunk: its halo rides along
+      const int c0 = i_c << 6;
+      const bool src2 = c0 >= p.Cin;
+      const int Cs = src2 ? p.Cin2 : p.Cin;
+      const int soff = (c0 - (src2 ? p.Cin : 0)) * 2;
+      char* hdst = Hs + (i_c & 1) * HALO_BYTES + wave * 1024;
+#pragma unroll
+      for (int ps = 0; ps < HP; ++ps) {
+        const unsigned off = h_pix[ps] >= 0 ? (unsigned)h_pix[ps] * (unsigned)(Cs * 2) + kchunk * 16 : OOB;
+        if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+      }
+    }
+    const int ksoff = live ? (i_tap * p.Ctot + (i_c << 6)) * 2 : 0;
+#pragma unroll
+    for (int ps = 0; ps < W_PASSES; ++ps)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(bdst + ps * (RPP * 128)), 16, live ? b_off[ps] : OOB, ksoff, 0, 0);
+    if (live) {
+      if (++i_tap == 9) { i_tap = 0; ++i_c; }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lrow = lane & 15, lq = lane >> 4;
+  // halo row of this lane's pixel in each 16-pixel MFMA sub-tile (tap (0,0) = halo origin, i.e. input pixel (-1,-1))
+  int a_hp[MI];
+  {
+    const FastDiv fd_w = p.fd_ow;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int pl = wm * (BM / WM) + i * 16 + lrow;
+      const int ly = fdiv(pl, fd_w), lx = pl - ly * W;
+      a_hp[i] = ly * HW2 + lx;
+    }
+  }
+
+  auto mma_tap = [&](const char* As, const char* Bs, int tap_off) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ks * 4 + lq;
+      bf16x8 af[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = a_hp[i] + tap_off;
+        af[i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + swz(r, ch) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int r = wn * (BN / WN) + j * 16 + lrow;
+        wf[j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + swz(r, ch) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(s, s);
+  {
+    int st = 0, st_fill = D;
+    int c_c = 0, c_tap = 0, c_dy = 0, c_dx = 0;          // compute-side cursor
+    for (int item = 0; item < nitems; ++item) {
+      // item's data (and its halo, if it opens a chunk) must have landed; the D-1 younger items may still be in flight,
+      // and they carry HP more DMA instructions when one of them opens a chunk
+      bool halo_young = false;
+#pragma unroll
+      for (int d = 1; d < D; ++d) {
+        const int t = c_tap + d;
+        halo_young = halo_young || ((t == 9 || t == 18) && item + d < nitems);
+      }
+      if (halo_young) wait_vmcnt<(D - 1) * W_PASSES + HP>(); else wait_vmcnt<(D - 1) * W_PASSES>();
+      __builtin_amdgcn_s_barrier();
+      issue(item + D, st_fill);
+      mma_tap(Hs + (c_c & 1) * HALO_BYTES, Bring + st * BSTAGE, c_dy * HW2 + c_dx);
+      st = (st + 1 == S) ? 0 : st + 1;
+      st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
+      ++c_tap;
+      if (++c_dx == 3) { c_dx = 0; ++c_dy; }
+      if (c_tap == 9) { c_tap = 0; c_dy = 0; ++c_c; }
+    }
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // rows of this tile past the bottom of the image alias the next image's first rows: cut M for the epilogue's bound checks
+  IgemmDev q = p;
+  q.M = min(p.M, min(m0 + BM, (img + 1) * p.OHW));
+  igemm_epilogue<BM, BN, MI, NI, false, NT>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, int HP, int S>
+int launch_halo(const IgemmDev& d, hipStream_t st) {
+  constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128;
+  constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_done = false;
+  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { aldm_set_error("igemm_halo: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int rows_pt = BM / d.OW;
+  if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
+    aldm_set_error("igemm_halo: image width %d does not fit the %dx%d halo tile", d.OW, BM, BN);
+    return ALDM_E_UNSUPPORTED;
+  }
+  IgemmDev dd = d;
+  dd.tiles_n = cdiv(d.N, BN);
+  dd.fd_halo = make_fastdiv((unsigned)(d.OW + 2));
+  const int tpi = cdiv(d.OH, rows_pt);
+  dim3 grid(d.B * tpi * dd.tiles_n, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dd);
+  return aldm_launch_status("igemm_halo");
+}
+
+}  // namespace aldm_igemm_detail
+
+// tile: ALDM_TILE_HALO_128x128 or ALDM_TILE_HALO_64x128.  The caller (aldm_igemm) has validated the generic arguments.
+int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, hipStream_t st) {
+  using namespace aldm_igemm_detail;
+  const bool ok = d.KH == 3 && d.KW == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh == 1 && d.dw == 1 &&
+                  d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.dilate == 0 && d.splits <= 1 &&
+                  !d.ln_s && !d.geglu && d.x_bytes < 0x80000000u && d.x2_bytes < 0x80000000u &&
+                  (d.UH == 0 || (d.UH == 2 * d.IH && d.UW == 2 * d.IW)) && d.OH == (d.UH ? d.UH : d.IH) && d.OW == (d.UW ? d.UW : d.IW);
+  if (!ok) {
+    aldm_set_error("igemm_halo: needs a 3x3 / stride 1 / pad 1 conv on the LDS-DMA path (Cin %% 64 == 0, no gather activation, no split-K)");
+    return ALDM_E_UNSUPPORTED;
+  }
+  if (tile == ALDM_TILE_HALO_128x128) {
+    if (ring == 2) return launch_halo<128, 128, 4, 2, 3, 2>(d, st);
+    if (ring == 4) return launch_halo<128, 128, 4, 2, 3, 4>(d, st);
+    return launch_halo<128, 128, 4, 2, 3, 3>(d, st);
+  }
+  if (ring == 2) return launch_halo<64, 128, 2, 4, 2, 2>(d, st);
+  if (ring == 4) return launch_halo<64, 128, 2, 4, 2, 4>(d, st);
+  return launch_halo<64, 128, 2, 4, 2, 3>(d, st);
+}

@@ -187,7 +187,15 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     return max(2, min(want, fit))
 
 
-TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128)}
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128)}
+HALO_ROWS = {7: 192, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip)
+
+
+def halo_tiles(OW, eligible):
+    """Halo tiles able to take a 3x3/s1/p1 conv whose output is OW wide: BM a multiple of OW and the halo within capacity."""
+    if not eligible:
+        return []
+    return [t for t in (7, 8) if TILE_DIMS[t][0] % OW == 0 and (TILE_DIMS[t][0] // OW + 2) * (OW + 2) <= HALO_ROWS[t]]
 
 # ---- measured launch configurations ------------------------------------------------------------------------------
 # "Measure, don't guess": tools/autotune.py picks (tile, ring, splits) per distinct GEMM in two stages and writes
@@ -230,7 +238,7 @@ class Tuner:
         self.slot = None         # stage 2: which shortlist slot this pass runs
 
     # ---- stage 1 ----
-    def isolated(self, a, key, M, pw, ktiles, can_split, forced_splits, fast_path, has_vt, device):
+    def isolated(self, a, key, M, pw, ktiles, can_split, forced_splits, fast_path, has_vt, device, halo=()):
         lib = _lib.load()
         default = heuristic_cfg(M, pw, ktiles, can_split, fast_path, has_vt, forced_splits)
         cands = []
@@ -246,6 +254,8 @@ class Tuner:
             for sp in sp_list:
                 for rg in ((2, 3) if t == 6 else (2, 3, 4)):
                     cands.append((t, rg, sp))
+        if forced_splits in (None, 1):
+            cands += [(t, rg, 1) for t in halo for rg in (2, 3, 4)]
         max_sp = max(c[2] for c in cands)
         ws = _workspace(max_sp * M * pw.N * 4, device) if max_sp > 1 else None
         results = []
@@ -301,7 +311,7 @@ def save_tuned(path=TUNED_PATH):
                    "igemm": {k: list(v) for k, v in sorted(TUNED.items())}}, f, indent=0)
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event).
 # Events are recorded on the stream the kernel is launched on.
@@ -410,11 +420,14 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         cfg = TUNED.get(key)
         tuning = TUNER is not None and not torch.cuda.is_current_stream_capturing()
         if tuning:
-            cfg = TUNER.choose(key, a, M, pw, ktiles, can_split and splits is None, splits, fast_path, vt is not None, x.device)
+            halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
+                              and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None
+                              and (up_size is None or up_size == (2 * IH, 2 * IW)))
+            cfg = TUNER.choose(key, a, M, pw, ktiles, can_split and splits is None, splits, fast_path, vt is not None, x.device, halo)
         if cfg is not None:
             tile, ring, splits = cfg
     if splits is None:
-        splits = auto_splits(M, pw.N, ktiles) if can_split else 1
+        splits = auto_splits(M, pw.N, ktiles) if (can_split and tile not in HALO_ROWS) else 1
     if tile == 0:
         tile = heuristic_cfg(M, pw, ktiles, can_split, fast_path, vt is not None, splits)[0]
     if not ring:

@@ -59,6 +59,58 @@ def test_conv3x3(ops, B, Cin, Cout, H, W, stride, tile):
     close(to_nchw(y), want)
 
 
+@pytest.mark.parametrize("tile", [7, 8])
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,up", [
+    (2, 128, 0, 128, 50, 16, False),      # level-0 shape, whole tiles
+    (3, 64, 0, 128, 37, 16, False),       # ragged height: the last tile of every image is partial
+    (2, 128, 64, 256, 21, 8, False),      # virtual concat, two N tiles, W = 8 (16-pixel MFMA rows span two image rows)
+    (1, 192, 0, 40, 10, 8, False),        # Cout below the tile width, 3 channel chunks
+    (2, 64, 0, 64, 14, 16, True),         # nearest 2x up-sampling folded into the gather (7x8 -> 14x16)
+    (1, 256, 128, 128, 250, 16, False),   # config-2 level-0 up-block conv of one image
+])
+def test_conv3x3_halo_tiles(ops, tile, B, C1, C2, Cout, H, W, up):
+    """3x3/s1/p1 conv through the LDS-halo kernel == F.conv2d, incl. time-embedding row bias, residual and SiLU epilogue."""
+    g = torch.Generator().manual_seed(7)
+    ih, iw = (H // 2, W // 2) if up else (H, W)
+    x1 = bf(torch.randn(B, C1, ih, iw, generator=g))
+    x2 = bf(torch.randn(B, C2, ih, iw, generator=g)) if C2 else None
+    w = bf(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2)))
+    b = torch.randn(Cout, generator=g)
+    rb = torch.randn(B, Cout, generator=g)
+    r = bf(torch.randn(B, Cout, H, W, generator=g))
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if up:
+        xin = F.interpolate(xin, size=(H, W), mode="nearest")
+    want = F.conv2d(xin, w, b, padding=1) + rb[:, :, None, None] + r
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    kw = dict(x2=(nhwc(x2) if C2 else None), pad=(1, 1), up_size=((H, W) if up else None), rowbias=rb.to(DEV), rowbias_ld=Cout,
+              res=nhwc(r), tile=tile)
+    y = ops.conv(nhwc(x1), pw, **kw)
+    assert y.shape == (B, H, W, Cout)
+    close(to_nchw(y), want)
+    base = ops.conv(nhwc(x1), pw, **dict(kw, tile=2))
+    assert float((y.float() - base.float()).abs().max()) <= 2e-2 * float(want.abs().max())     # same math as the generic kernel
+    for ring in (2, 4):
+        assert torch.equal(ops.conv(nhwc(x1), pw, **dict(kw, ring=ring)), y)                         # ring depth never changes results
+
+
+def test_conv3x3_halo_rejects_unsupported(ops):
+    from audioldm_with_lora_amd._lib import AldmError
+    g = torch.Generator().manual_seed(8)
+    x = nhwc(bf(torch.randn(1, 64, 12, 16, generator=g)))
+    pw3 = ops.pack_conv(torch.randn(64, 64, 3, 3, device=DEV) / 24, None)
+    pw1 = ops.pack_conv(torch.randn(64, 64, 1, 1, device=DEV) / 8, None)
+    with pytest.raises(AldmError):
+        ops.conv(x, pw1, tile=7)                                   # not a 3x3
+    with pytest.raises(AldmError):
+        ops.conv(x, pw3, pad=(1, 1), stride=(2, 2), tile=7)        # strided
+    with pytest.raises(AldmError):
+        ops.conv(x, pw3, pad=(1, 1), tile=7, splits=2)             # split-K
+    x5 = nhwc(bf(torch.randn(1, 64, 12, 5, generator=g)))
+    with pytest.raises(AldmError):
+        ops.conv(x5, pw3, pad=(1, 1), tile=8)                      # width 5 does not divide the tile
+
+
 def test_conv_splitk_matches(ops):
     g = torch.Generator().manual_seed(1)
     x = bf(torch.randn(2, 320, 16, 2, generator=g))
