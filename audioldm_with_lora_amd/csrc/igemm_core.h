@@ -219,6 +219,123 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
                                                const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
   float* Cs = reinterpret_cast<float*>(smem);
+
+  // Standard path (no V^T tile, no split-K, no GEGLU).  A thread keeps ONE 8-column group (NT % (BN/8) == 0) and walks down
+  // the rows, so the bias / LayerNorm column vectors are loaded once.  Rows are handled CH at a time in two phases: phase A
+  // issues every global read the rows need (time-embedding row bias, residuals), phase B does the arithmetic and the stores,
+  // so a thread pays one memory round trip per CH rows instead of one per row -- and phase A of the first CH rows is issued
+  // HERE, before the accumulators make their LDS round trip, which hides that latency behind the transposition.
+  // Measured in a replayed graph (MI355X): epilogue of the 8-wave 128x128 tile 10.2 -> 5.8 us with the two-phase walk.
+  constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
+  static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
+  const int r0 = tid / GPR, c = (tid % GPR) * 8, n = n0 + c;
+  const bool std_path = !(VT && vt_wg) && p.splits <= 1 && !p.geglu;
+  const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
+  const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
+  float colb[8], lns[8];
+  long long rowo[CH];
+  bool ok[CH];
+  f32x4 rb0[CH], rb1[CH];
+  bf16x8 r1[CH], r2[CH];
+  auto phaseA = [&](int it0) {                               // addresses + every global read of rows it0 .. it0+CH-1
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int m = m0 + r0 + (it0 + u) * RSTEP;
+      ok[u] = m < p.M;
+      rb0[u] = rb1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      r1[u] = r2[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      rowo[u] = 0;
+      if (!ok[u]) continue;
+      const int b = fdiv(m, p.fd_ohw);
+      const int pix = m - b * p.OHW;
+      rowo[u] = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
+      if (p.rowbias) {
+        const float* rb = p.rowbias + (long long)b * p.rowbias_ld + n;
+        if (rbvec) {
+          rb0[u] = *reinterpret_cast<const f32x4*>(rb);
+          rb1[u] = *reinterpret_cast<const f32x4*>(rb + 4);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (n + q < p.N) rb0[u][q] = rb[q];
+            if (n + 4 + q < p.N) rb1[u][q] = rb[4 + q];
+          }
+        }
+      }
+      if (vec) {
+        if (p.res) r1[u] = *reinterpret_cast<const bf16x8*>(p.res + rowo[u] + n);
+        if (p.res2) r2[u] = *reinterpret_cast<const bf16x8*>(p.res2 + rowo[u] + n);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (p.res && n + q < p.N) r1[u][q] = p.res[rowo[u] + n + q];
+          if (p.res2 && n + q < p.N) r2[u][q] = p.res2[rowo[u] + n + q];
+        }
+      }
+    }
+  };
+  auto phaseB = [&](int it0) {                               // arithmetic + stores
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (!ok[u]) continue;
+      const int r = r0 + (it0 + u) * RSTEP;
+      const float* src = Cs + r * E::LD + c;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[q];
+      if (lnst) {
+        const float mu = lnst[r], rs = lnst[BM + r];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = rs * (v[q] - mu * lns[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] += colb[q] + rb0[u][q]; v[4 + q] += colb[4 + q] + rb1[u][q]; }
+      if (p.out_act) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.out_act, p.out_slope);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (v[q] + (float)r1[u][q]) * p.alpha + (float)r2[u][q];
+      if (p.out2) {
+        bf16* o2 = p.out2 + rowo[u] + n;
+        bf16x8 t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (bf16)apply_act(v[q], p.post_act, p.post_slope);
+        if (vec) *reinterpret_cast<bf16x8*>(o2) = t;
+        else
+          for (int q = 0; q < 8; ++q) if (n + q < p.N) o2[q] = t[q];
+      } else if (p.post_act) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.post_act, p.post_slope);
+      }
+      if (p.out_f32) {
+        float* o = reinterpret_cast<float*>(p.out) + rowo[u] + n;
+        if (vec) {
+          *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = v[q];
+        }
+      } else {
+        bf16* o = reinterpret_cast<bf16*>(p.out) + rowo[u] + n;
+        bf16x8 t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (bf16)v[q];
+        if (vec) *reinterpret_cast<bf16x8*>(o) = t;       // (non-temporal stores: -7 % on isolated GEMMs, +1.2 % on the whole step)
+        else
+          for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = t[q];
+      }
+    }
+  };
+  if (std_path && n < p.N) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      colb[q] = (p.bias && n + q < p.N) ? p.bias[n + q] : 0.f;
+      lns[q] = (lnst && n + q < p.N) ? p.ln_s[n + q] : 0.f;
+    }
+    phaseA(0);
+  }
+
   __syncthreads();                                           // every wave is done with the K-loop images
   if (VT && vt_wg) {
 #pragma unroll
@@ -306,119 +423,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
     return;
   }
-  // Standard path.  A thread keeps ONE 8-column group (NT % (BN/8) == 0) and walks down the rows, so the bias / LayerNorm
-  // column vectors are loaded once.  Rows are handled CH at a time in two phases -- first every global read the rows need
-  // (time-embedding row bias, residuals) is issued, then the arithmetic and the stores run -- so a thread pays one memory
-  // round trip per CH rows instead of one per row.  (Measured on the 8-wave 128x128 tile: epilogue 10.2 us -> see DESIGN.md.)
-  {
-    constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
-    static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
-    const int cg = tid % GPR, r0 = tid / GPR;
-    const int c = cg * 8, n = n0 + c;
-    if (n >= p.N) return;
-    const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
-    const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
-    float colb[8], lns[8];
+  // Standard path, second half: the first CH rows were prefetched before the LDS transposition (see the top of this function)
+  if (n >= p.N) return;
+  phaseB(0);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      colb[q] = (p.bias && n + q < p.N) ? p.bias[n + q] : 0.f;
-      lns[q] = (lnst && n + q < p.N) ? p.ln_s[n + q] : 0.f;
-    }
-#pragma unroll
-    for (int it0 = 0; it0 < ITERS; it0 += CH) {
-      long long rowo[CH];
-      bool ok[CH];
-      f32x4 rb0[CH], rb1[CH];
-      bf16x8 r1[CH], r2[CH];
-      // ---- phase A: addresses + every global read of these CH rows ----
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int m = m0 + r0 + (it0 + u) * RSTEP;
-        ok[u] = m < p.M;
-        rb0[u] = rb1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        r1[u] = r2[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        rowo[u] = 0;
-        if (!ok[u]) continue;
-        const int b = fdiv(m, p.fd_ohw);
-        const int pix = m - b * p.OHW;
-        rowo[u] = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
-        if (p.rowbias) {
-          const float* rb = p.rowbias + (long long)b * p.rowbias_ld + n;
-          if (rbvec) {
-            rb0[u] = *reinterpret_cast<const f32x4*>(rb);
-            rb1[u] = *reinterpret_cast<const f32x4*>(rb + 4);
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (n + q < p.N) rb0[u][q] = rb[q];
-              if (n + 4 + q < p.N) rb1[u][q] = rb[4 + q];
-            }
-          }
-        }
-        if (vec) {
-          if (p.res) r1[u] = *reinterpret_cast<const bf16x8*>(p.res + rowo[u] + n);
-          if (p.res2) r2[u] = *reinterpret_cast<const bf16x8*>(p.res2 + rowo[u] + n);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (p.res && n + q < p.N) r1[u][q] = p.res[rowo[u] + n + q];
-            if (p.res2 && n + q < p.N) r2[u][q] = p.res2[rowo[u] + n + q];
-          }
-        }
-      }
-      // ---- phase B: arithmetic + stores ----
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        if (!ok[u]) continue;
-        const int r = r0 + (it0 + u) * RSTEP;
-        const float* src = Cs + r * E::LD + c;
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = src[q];
-        if (lnst) {
-          const float mu = lnst[r], rs = lnst[BM + r];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = rs * (v[q] - mu * lns[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] += colb[q] + rb0[u][q]; v[4 + q] += colb[4 + q] + rb1[u][q]; }
-        if (p.out_act) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.out_act, p.out_slope);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (v[q] + (float)r1[u][q]) * p.alpha + (float)r2[u][q];
-        if (p.out2) {
-          bf16* o2 = p.out2 + rowo[u] + n;
-          bf16x8 t;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) t[q] = (bf16)apply_act(v[q], p.post_act, p.post_slope);
-          if (vec) *reinterpret_cast<bf16x8*>(o2) = t;
-          else
-            for (int q = 0; q < 8; ++q) if (n + q < p.N) o2[q] = t[q];
-        } else if (p.post_act) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.post_act, p.post_slope);
-        }
-        if (p.out_f32) {
-          float* o = reinterpret_cast<float*>(p.out) + rowo[u] + n;
-          if (vec) {
-            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = v[q];
-          }
-        } else {
-          bf16* o = reinterpret_cast<bf16*>(p.out) + rowo[u] + n;
-          bf16x8 t;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) t[q] = (bf16)v[q];
-          if (vec) *reinterpret_cast<bf16x8*>(o) = t;
-          else
-            for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = t[q];
-        }
-      }
-    }
+  for (int it0 = CH; it0 < ITERS; it0 += CH) {
+    phaseA(it0);
+    phaseB(it0);
   }
 }
 
