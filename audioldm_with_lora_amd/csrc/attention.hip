@@ -45,8 +45,23 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = (blockIdx.x * NW + wave) * 32;
+  // XCD-aware order: the dispatcher deals workgroups round-robin over the 8 XCDs, so with the natural order every XCD's L2
+  // pulls every (batch, head)'s K / V^T (PMC: 70 MB fetched per launch for 16 MB of operands at N = 1000).  Give each XCD
+  // whole (batch, head) pairs instead: all query blocks of a pair then share one L2.  Bijective when pairs % 8 == 0.
+  int qblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  {
+    const int nq = gridDim.x, H = gridDim.y, npairs = H * gridDim.z;
+    if ((npairs & 7) == 0) {
+      const int L = blockIdx.x + nq * (blockIdx.y + H * blockIdx.z);
+      const int xcd = L & 7, slot = L >> 3;
+      const int pl = slot / nq;
+      qblk = slot - pl * nq;
+      const int pair = pl * 8 + xcd;
+      b = pair / H;
+      head = pair - b * H;
+    }
+  }
+  const int q0 = (qblk * NW + wave) * 32;
   const bf16* qb = q + (long long)b * N * ldq + head * D;
   const bf16* kb = k + (long long)b * N * ldk + head * D;
   const bf16* vb = vt + (long long)b * vt_bs + (long long)head * D * vt_ld;
@@ -54,10 +69,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // keys 0 .. Nk-1 of this batch item take part (right-padded text batches pass their true lengths; the key loop
   // then stops at the last valid tile instead of masking 512-token padding)
   const int Nk = kv_len ? max(1, min(kv_len[b], N)) : N;
-  if (kv_len && (int)blockIdx.x * NW * 32 >= Nk) {
+  if (kv_len && qblk * NW * 32 >= Nk) {
     // every query of this workgroup is padding: its rows are never read as keys, so write zeros and leave
     for (int i = tid; i < NW * 32 * (D / 4); i += T) {
-      const int row = blockIdx.x * NW * 32 + i / (D / 4), c4 = i % (D / 4);
+      const int row = qblk * NW * 32 + i / (D / 4), c4 = i % (D / 4);
       if (row < N) *reinterpret_cast<uint2*>(out + ((long long)b * N + row) * out_ld + head * D + c4 * 4) = make_uint2(0u, 0u);
     }
     return;

@@ -67,6 +67,22 @@ __device__ __forceinline__ bf16x8 read_tok_frag(const char* tile, int row, int s
 }
 
 // ---- dQ ------------------------------------------------------------------------------------------
+// XCD-aware (block, head, batch) order, as in attention.hip: every XCD gets whole (batch, head) pairs so the pair's K / V /
+// Q / dO tiles are fetched into ONE L2 instead of all eight.  Bijective when (heads * batch) % 8 == 0, identity otherwise.
+__device__ __forceinline__ void xcd_pair_order(int& blk, int& head, int& b) {
+  const int nq = gridDim.x, H = gridDim.y, npairs = H * gridDim.z;
+  blk = blockIdx.x; head = blockIdx.y; b = blockIdx.z;
+  if ((npairs & 7) == 0) {
+    const int L = blockIdx.x + nq * (blockIdx.y + H * blockIdx.z);
+    const int xcd = L & 7, slot = L >> 3;
+    const int pl = slot / nq;
+    blk = slot - pl * nq;
+    const int pair = pl * 8 + xcd;
+    b = pair / H;
+    head = pair - b * H;
+  }
+}
+
 template <int DP, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                               const bf16* __restrict__ v, int ld,
@@ -83,8 +99,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z, H = gridDim.y;
-  const int q0 = (blockIdx.x * NW + wave) * 32;
+  int blk, head, b;
+  xcd_pair_order(blk, head, b);
+  const int H = gridDim.y;
+  const int q0 = (blk * NW + wave) * 32;
   const float c = scale * 1.44269504088896340736f;
   const long long rowbase = (long long)b * N;
   const bf16* qb = q + rowbase * ld + head * D;
@@ -191,8 +209,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const bf16* __res
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z, H = gridDim.y;
-  const int kv0 = (blockIdx.x * NW + wave) * 32;
+  int blk, head, b;
+  xcd_pair_order(blk, head, b);
+  const int H = gridDim.y;
+  const int kv0 = (blk * NW + wave) * 32;
   const float c = scale * 1.44269504088896340736f;
   const long long rowbase = (long long)b * N;
   const bf16* qb = q + rowbase * ld + head * D;

@@ -109,7 +109,7 @@ class DenoiseEngine:
         torch.cuda.synchronize()
         if self.use_graph:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
                 self._one_step()
         for dst, src in zip([self.x] + self.x_in + [self.step_idx, self.t_buf], [saved[0]] + saved[1] + [saved[2], saved[3]]):
             dst.copy_(src)

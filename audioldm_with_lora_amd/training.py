@@ -456,7 +456,7 @@ class LoraTrainer:
         self._static = tuple(a.clone() for a in args)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
             self._fwd_bwd(*self._static)
         self.graph.replay()
         return f.grads[f.n:]
