@@ -445,6 +445,34 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const bf16* __res
   }
 }
 
+// Fast path of the same transpose (ld_in, C multiples of 8; 16-byte aligned input): a wave moves a [64 tokens][32 channels]
+// block -- coalesced 16-byte row loads into a 64-byte-row LDS slab, then the transposing LDS read (ds_read_b64_tr_b16, see
+// tr_frag) hands every lane 8 consecutive TOKENS of one channel = one 16-byte token-major store.  4 waves = 128 channels.
+__global__ __launch_bounds__(256) void transpose_tokens_tr_kernel(const bf16* __restrict__ in, int ld_in, int N, int C, int Npad,
+                                                                  bf16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char slab[4][64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 128 + wave * 32;
+  char* sl = slab[wave];
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                       // 64 rows x 4 chunks of 16 B = 256 chunks, 4 per lane
+    const int idx = lane + 64 * i, row = idx >> 2, ch = idx & 3;
+    const int n = n0 + row, cc = c0 + ch * 8;
+    bf16x8 v = zero8;
+    if (n < N && cc < C) v = *reinterpret_cast<const bf16x8*>(in + ((long long)b * N + n) * ld_in + cc);
+    *reinterpret_cast<bf16x8*>(sl + row * 64 + ch * 16) = v;
+  }
+  __syncthreads();                                    // (wave-private slab; the barrier keeps EXEC full for the tr reads)
+  const int c = c0 + (lane & 31), hh = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < 64; kb += 16) {
+    const bf16x8 v = tr_frag(sl, lane, kb);
+    const int n = n0 + kb + 8 * hh;
+    if (c < C && n < Npad) *reinterpret_cast<bf16x8*>(out + ((long long)b * C + c) * Npad + n) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                        long long n, float gscale, bf16* __restrict__ dpred,
                                                        float* __restrict__ loss) {
@@ -555,6 +583,11 @@ extern "C" int aldm_lora_pack(const void* jobs_dev, int njobs, void* stream) {
 
 extern "C" int aldm_transpose_tokens(const void* in, int ld_in, int B, int N, int C, int Npad, void* out, void* stream) {
   ALDM_CHECK_ARG(in && out && B > 0 && N > 0 && C > 0 && Npad >= N, "transpose_tokens: bad args");
+  if (ld_in % 8 == 0 && C % 8 == 0 && Npad % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(transpose_tokens_tr_kernel, dim3(cdiv(Npad, 64), cdiv(C, 128), B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)in, ld_in, N, C, Npad, (bf16*)out);
+    return aldm_launch_status("transpose_tokens");
+  }
   hipLaunchKernelGGL(transpose_tokens_kernel, dim3(cdiv(Npad, 64), cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)in, ld_in, N, C, Npad, (bf16*)out);
   return aldm_launch_status("transpose_tokens");

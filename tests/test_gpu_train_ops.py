@@ -209,3 +209,18 @@ def test_tn_small_mfma_and_scalar_paths(ops, M, Rp, Qc, ldq):
             close(got[p_, :Qc - half], 0.5 * want[p_, half:], rtol=1e-3, atol=tol)
             assert float(got[p_, Qc - half:].abs().max()) == 0.0
     assert float(flat[Rp * Qc:].abs().max()) == 0.0        # nothing written past the table's windows
+
+
+@pytest.mark.parametrize("B,N,C,ld", [(2, 100, 96, 96), (8, 64, 640, 1920), (1, 1024, 256, 768), (3, 37, 40, 40), (2, 50, 20, 20), (2, 9, 12, 36)])
+def test_transpose_tokens_fast_and_generic_paths(ops, B, N, C, ld):
+    """[B*N][ld] row-major (first C columns) -> [B][C][Npad] token-major with zero padding; C, ld multiples of 8 take the
+    transposing-LDS-read kernel, anything else the scalar one."""
+    g = torch.Generator().manual_seed(N + C)
+    full = torch.randn(B * N, ld, generator=g).to(torch.bfloat16)
+    npad = (N + 7) // 8 * 8
+    dev = full.to(DEV)
+    got = ops.transpose_tokens(dev[:, :C] if ld != C else dev, B, N, C).cpu()
+    assert got.shape == (B, C, npad)
+    want = torch.zeros(B, C, npad, dtype=torch.bfloat16)
+    want[:, :, :N] = full[:, :C].view(B, N, C).transpose(1, 2)
+    assert torch.equal(got, want)
