@@ -126,6 +126,33 @@ def cpu_baseline(batch, height, width, rank_lora, max_seconds=30.0):
                       f"after 1 warm-up; median {med:.2f} s/step"}
 
 
+
+def bench_decode(batch, height, width, reps=3):
+    """VAE latent->mel decode + HiFi-GAN vocoder for the `batch` clips (random-init weights of the real architecture):
+    the remainder of AudioLDMPipeline.__call__ after the loop [REF script/inference/generate_audio.py:47-52]."""
+    from audioldm_with_lora_amd.vae import AutoencoderKL
+    from audioldm_with_lora_amd.vocoder import SpeechT5HifiGan
+    torch.manual_seed(99)
+    vae, voc = AutoencoderKL().cuda(), SpeechT5HifiGan().cuda()
+    z = torch.randn(batch, 8, height, width, device="cuda")
+    t = {}
+    for name, fn in (("vae_decode_ms", lambda: vae.decode(z).sample), ("vocoder_ms", None)):
+        if fn is None:
+            mel = vae.decode(z).sample.squeeze(1)
+            fn = lambda: voc(mel)
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) / reps * 1e3
+    assert torch.isfinite(out).all()
+    del vae, voc
+    torch.cuda.empty_cache()
+    return t
+
+
 def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
     """Config 3/4: LoRA fine-tune step (add_noise -> UNet fwd -> MSE -> bwd -> flat all-reduce -> AdamW) on synthetic
     10.24 s mel latents [8, 8, 256, 16] per GPU; clips/s = world * batch / step time."""
@@ -233,11 +260,16 @@ def main():
         dt = float(tmax.item())
     assert torch.isfinite(eng.x).all(), "latents diverged"
 
+    decode = None
+    if not args.no_train and rank == 0:
+        eng.graph = None
+        torch.cuda.empty_cache()
+        decode = bench_decode(args.batch, H, W)
     train = None
     if not args.no_train:
         eng.graph = None
         torch.cuda.empty_cache()
-        train = bench_train(world, rank)
+        train = bench_train(world, rank, rank_lora=(8 if world == 1 else 16))     # config 3 on one GPU, config 4 (rank 16) data-parallel
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
         prof = kernel_profile(eng)
@@ -274,6 +306,13 @@ def main():
         }
         if train is not None:
             out["train"] = train
+        if decode is not None:
+            loop_ms = NSTEPS * dt / args.steps * 1e3
+            total_ms = loop_ms + decode["vae_decode_ms"] + decode["vocoder_ms"]
+            out["end_to_end"] = {"clips_per_sec": round(world * args.batch / (total_ms * 1e-3), 3), "clip_seconds": 10.0,
+                                 "ddim_steps": NSTEPS, "loop_ms": round(loop_ms, 1), "vae_decode_ms": round(decode["vae_decode_ms"], 2),
+                                 "vocoder_ms": round(decode["vocoder_ms"], 2),
+                                 "note": "loop_ms = 200 x the measured step; decode legs run eagerly (not graph-captured)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, H, W, args.rank)
         print(json.dumps(out))
