@@ -184,3 +184,41 @@ def test_tuned_table_is_well_formed():
         if " vt1 " in key or " ln1 " in key:
             assert splits == 1
     assert ops.TUNED == {k: tuple(v) for k, v in table.items()} or os.environ.get("ALDM_NO_TUNED") == "1"
+
+
+def test_collate_contract_and_caption_lengths_host_logic():
+    """the trainer's input batch has the reference collate_fn's keys / shapes / dtypes
+    [REF script/train/train_audioldm_lora.py:415-420]; caption lengths come from a right-padded mask only."""
+    import pytest
+    import torch
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.script.train import synthetic_batch
+    b = synthetic_batch(3, torch.Generator().manual_seed(0))
+    assert b["log_mel_spec"].shape == (3, 1, 1024, 64) and b["log_mel_spec"].dtype == torch.float32
+    assert b["input_ids"].shape == (3, 1, 512) and b["input_ids"].dtype == torch.int64
+    assert b["attention_mask"].shape == (3, 1, 512)
+    ids, mask = b["input_ids"].squeeze(1), b["attention_mask"].squeeze(1)
+    lens = ClapTextModelWithProjection._lengths(ids, mask)
+    assert lens.dtype == torch.int32 and lens.tolist() == mask.sum(1).tolist() and 8 <= int(lens.min()) and int(lens.max()) <= 64
+    assert bool((ids[mask == 0] == 1).all()) and bool((ids[:, 0] == 0).all())          # <pad> = 1 after the caption, <s> = 0 first
+    assert ClapTextModelWithProjection._lengths(ids, None).tolist() == [512] * 3
+    bad = mask.clone()
+    bad[0, 0] = 0                                                                          # left padding
+    with pytest.raises(ValueError):
+        ClapTextModelWithProjection._lengths(ids, bad)
+    with pytest.raises(ValueError):
+        ClapTextModelWithProjection._lengths(ids, torch.zeros_like(mask))                  # an empty caption
+
+
+def test_clap_text_manifest_equals_oracle_and_no_cpu_forward():
+    import pytest
+    import torch
+    from audioldm_with_lora_amd._lib import AldmError
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.configs import tiny_clap_text
+    from oracle.clap_text import ClapTextModelWithProjection as OClap
+    m, o = ClapTextModelWithProjection(**tiny_clap_text()), OClap(**tiny_clap_text())
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    assert any(k == "text_model.encoder.layer.0.attention.self.query.weight" for k in m.state_dict())
+    with pytest.raises(AldmError):
+        m(input_ids=torch.zeros(1, 8, dtype=torch.long))
