@@ -35,7 +35,8 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
                                                                    const bf16* __restrict__ dy, int HW, int C1, int C2,
                                                                    int groups, float eps, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
-                                                                   bf16* __restrict__ dx, bf16* __restrict__ dx2, int accumulate) {
+                                                                   bf16* __restrict__ dx, bf16* __restrict__ dx2,
+                                                                   const bf16* dx_acc, const bf16* dx2_acc) {
   __shared__ float red[16];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -120,15 +121,16 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
         }
         o[k] = (bf16)(rstd * (dz * gamma[c + k] - s1 - xh * s2));
       }
-      // accumulate bit 0 / 1: dx / dx2 already hold a gradient from another consumer of x / x2 -- add to it in place
+      // dx_acc / dx2_acc: the gradient x / x2 already received from their other consumers (residual / skip joins) -- added
+      // here instead of in a separate launch.  They may alias dx / dx2 (each element is read and written by one thread).
       if (c < C1) {
-        bf16x4* dst = reinterpret_cast<bf16x4*>(dx + ((long long)b * HW + pix) * C1 + c);
-        if (accumulate & 1) { const bf16x4 a = *dst; for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
-        *dst = o;
+        const long long off = ((long long)b * HW + pix) * C1 + c;
+        if (dx_acc) { const bf16x4 a = *reinterpret_cast<const bf16x4*>(dx_acc + off); for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
+        *reinterpret_cast<bf16x4*>(dx + off) = o;
       } else if (dx2) {
-        bf16x4* dst = reinterpret_cast<bf16x4*>(dx2 + ((long long)b * HW + pix) * C2 + (c - C1));
-        if (accumulate & 2) { const bf16x4 a = *dst; for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
-        *dst = o;
+        const long long off = ((long long)b * HW + pix) * C2 + (c - C1);
+        if (dx2_acc) { const bf16x4 a = *reinterpret_cast<const bf16x4*>(dx2_acc + off); for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
+        *reinterpret_cast<bf16x4*>(dx2 + off) = o;
       }
     }
   }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
 constexpr int LN_MAXC = 4;
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int M,
                                                             int C, const float* __restrict__ gamma, float eps,
-                                                            bf16* __restrict__ dx, int accumulate) {
+                                                            bf16* __restrict__ dx, const bf16* dx_acc) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         const float xh = ((float)v[i][k] - mean) * rstd;
         r[k] = (bf16)(rstd * ((float)d[i][k] * gamma[ch * 8 + k] - s1 - xh * s2));
       }
-      if (accumulate) {                        // dx already holds the residual stream's gradient: add in place
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + ch * 8);
+      if (dx_acc) {                            // the residual stream's gradient from its other consumers (may alias dx)
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dx_acc + (long long)row * C + ch * 8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) r[k] = (bf16)((float)r[k] + (float)a[k]);
       }
@@ -344,16 +346,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* slab, int lane, int kbase)
 }
 
 template <int RP>
-__global__ __launch_bounds__(256) void tn_mfma_kernel(const bf16* __restrict__ P, const bf16* __restrict__ Q, int M, int ldq,
-                                                      int Qc, const TnRow* __restrict__ rows, int m_per_block) {
+__device__ __forceinline__ void tn_mfma_body(const bf16* __restrict__ P, const bf16* __restrict__ Q, int M, int ldq, int Qc,
+                                             const TnRow* __restrict__ rows, int m_per_block, int bx, int by, char* smem) {
   constexpr int PT = RP / 32;                    // 32-row p tiles
   constexpr int SLAB = 32 * 64;                  // bytes of one [32 m][32 col] bf16 slab
   constexpr int STAGE = (PT + 4) * SLAB;
   constexpr int PCH = PT * 128;                  // 16-byte chunks of the P tile per stage
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q0 = blockIdx.x * 128;
-  const int mb = blockIdx.y * m_per_block, me = min(M, mb + m_per_block);
+  const int q0 = bx * 128;
+  const int mb = by * m_per_block, me = min(M, mb + m_per_block);
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 qreg[2], preg;
   auto prefetch = [&](int m0) {
@@ -414,6 +415,33 @@ __global__ __launch_bounds__(256) void tn_mfma_kernel(const bf16* __restrict__ P
         if (r.dst && q >= r.qlo && q < r.qhi) atomicAdd(r.dst + (long long)(q - r.qlo) * r.qstride, acc[t][i] * r.scale);
       }
   }
+}
+
+template <int RP>
+__global__ __launch_bounds__(256) void tn_mfma_kernel(const bf16* __restrict__ P, const bf16* __restrict__ Q, int M, int ldq,
+                                                      int Qc, const TnRow* __restrict__ rows, int m_per_block) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (RP / 32 + 4) * 32 * 64];
+  tn_mfma_body<RP>(P, Q, M, ldq, Qc, rows, m_per_block, blockIdx.x, blockIdx.y, smem);
+}
+
+// All LoRA-gradient products of one training step in ONE launch: the tape defers its 2 x 64 rank-r products to the end of
+// the backward pass and hands them over as a job table; a workgroup finds its job by binary search over the jobs' first
+// workgroup ids.  One launch instead of 128 (each ~2.5 us of launch floor plus ramp-up for ~1 us of HBM traffic), and the
+// whole GPU streams X / dY at once.
+struct TnJob { const bf16* P; const bf16* Q; const TnRow* rows; int M, ldq, Qc, qt, mpb, wg0; };
+template <int RP>
+__global__ __launch_bounds__(256) void tn_mfma_batched_kernel(const TnJob* __restrict__ jobs, int njobs) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (RP / 32 + 4) * 32 * 64];
+  const int wg = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {                                  // last job whose first workgroup id is <= wg (uniform across the block)
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].wg0 <= wg) lo = mid; else hi = mid - 1;
+  }
+  const TnJob j = jobs[lo];
+  const int local = wg - j.wg0;
+  const int by = local / j.qt, bx = local - by * j.qt;
+  tn_mfma_body<RP>(j.P, j.Q, j.M, j.ldq, j.Qc, j.rows, j.mpb, bx, by, smem);
 }
 
 struct PackJob { const float* src; bf16* dst; int rows, cols, src_ld, dst_ld, transpose; float scale; };
@@ -495,7 +523,7 @@ inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / p
 
 extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
                                   float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2,
-                                  int accumulate, void* stream) {
+                                  const void* dx_acc, const void* dx2_acc, void* stream) {
   ALDM_CHECK_ARG(x && dy && dx && gamma && beta && B > 0 && HW > 0, "groupnorm_bwd: bad args");
   const int C = C1 + C2;
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0 && (C2 == 0 || x2), "groupnorm_bwd: bad channels");
@@ -504,7 +532,7 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
 #define ALDM_GNB(QPT)                                                                                                  \
   hipLaunchKernelGGL(groupnorm_bwd_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
                      (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
-                     (bf16*)dx, (bf16*)dx2, accumulate)
+                     (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc)
   if (nquads <= 4 * GN_THREADS) ALDM_GNB(4);
   else if (nquads <= 8 * GN_THREADS) ALDM_GNB(8);
   else if (nquads <= 16 * GN_THREADS) ALDM_GNB(16);
@@ -514,10 +542,10 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
 }
 
 extern "C" int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx,
-                                  int accumulate, void* stream) {
+                                  const void* dx_acc, void* stream) {
   ALDM_CHECK_ARG(x && dy && dx && gamma && M > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "layernorm_bwd: bad args");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                     (const bf16*)dy, M, C, gamma, eps, (bf16*)dx, accumulate);
+                     (const bf16*)dy, M, C, gamma, eps, (bf16*)dx, (const bf16*)dx_acc);
   return aldm_launch_status("layernorm_bwd");
 }
 
@@ -573,6 +601,15 @@ extern "C" int aldm_tn_small(const void* P, int Rp, const void* Q, int ldq, int 
   else
     hipLaunchKernelGGL(tn_small_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)P, (const bf16*)Q, M, ldq, Qc, (const TnRow*)rows_dev, mpb);
   return aldm_launch_status("tn_small");
+}
+
+extern "C" int aldm_tn_batched(const void* jobs_dev, int njobs, int total_wgs, int Rp, void* stream) {
+  ALDM_CHECK_ARG(jobs_dev && njobs > 0 && total_wgs > 0 && (Rp == 32 || Rp == 64), "tn_batched: bad args");
+  if (Rp == 32)
+    hipLaunchKernelGGL(tn_mfma_batched_kernel<32>, dim3(total_wgs), dim3(256), 0, (hipStream_t)stream, (const TnJob*)jobs_dev, njobs);
+  else
+    hipLaunchKernelGGL(tn_mfma_batched_kernel<64>, dim3(total_wgs), dim3(256), 0, (hipStream_t)stream, (const TnJob*)jobs_dev, njobs);
+  return aldm_launch_status("tn_batched");
 }
 
 extern "C" int aldm_lora_pack(const void* jobs_dev, int njobs, void* stream) {

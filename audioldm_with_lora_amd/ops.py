@@ -634,31 +634,30 @@ def attention_bwd(qkv, qkvT, dO, O, lse, B, N, H, d):
     return dqkv
 
 
-def _into(buf, like):
+def _like(buf, like):
     assert buf.is_contiguous() and buf.numel() == like.numel() and buf.dtype == like.dtype
     return buf
 
 
-def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True, dx_into=None, dx2_into=None):
-    """dx (dx2) of act(group_norm(cat[x, x2])).  dx_into / dx2_into: existing gradient buffers to ADD into in place
-    (the tensor has other consumers); the returned tensors are then those buffers."""
+def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True, dx_add=None, dx2_add=None):
+    """dx (dx2) of act(group_norm(cat[x, x2])).  dx_add / dx2_add: gradients x / x2 already hold from their other consumers;
+    they are added inside the kernel (fresh output tensors, the inputs are not modified)."""
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    dx = torch.empty_like(x) if dx_into is None else _into(dx_into, x)
-    dx2 = None
-    if x2 is not None and need_dx2:
-        dx2 = torch.empty_like(x2) if dx2_into is None else _into(dx2_into, x2)
-    accumulate = (1 if dx_into is not None else 0) | (2 if (dx2 is not None and dx2_into is not None) else 0)
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x2) if (x2 is not None and need_dx2) else None
+    a1 = _like(dx_add, x) if dx_add is not None else None
+    a2 = _like(dx2_add, x2) if (dx2 is not None and dx2_add is not None) else None
     check(_lib.load().aldm_groupnorm_bwd(_p(x), _p(x2), _p(dy), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act,
-                                         _p(dx), _p(dx2), accumulate, _stream()), "aldm_groupnorm_bwd")
+                                         _p(dx), _p(dx2), _p(a1), _p(a2), _stream()), "aldm_groupnorm_bwd")
     return dx, dx2
 
 
-def layernorm_bwd(x2d, dy, gamma, eps=1e-5, dx_into=None):
+def layernorm_bwd(x2d, dy, gamma, eps=1e-5, dx_add=None):
     M, Cc = x2d.shape
-    dx = torch.empty_like(x2d) if dx_into is None else _into(dx_into, x2d)
-    check(_lib.load().aldm_layernorm_bwd(_p(x2d), _p(dy), M, Cc, _p(gamma), eps, _p(dx), int(dx_into is not None), _stream()),
-          "aldm_layernorm_bwd")
+    dx = torch.empty_like(x2d)
+    a = _like(dx_add, x2d) if dx_add is not None else None
+    check(_lib.load().aldm_layernorm_bwd(_p(x2d), _p(dy), M, Cc, _p(gamma), eps, _p(dx), _p(a), _stream()), "aldm_layernorm_bwd")
     return dx
 
 
@@ -693,6 +692,59 @@ def tn_small(P, Q, rows_dev, Qc=None):
     M, Rp = P.shape
     check(_lib.load().aldm_tn_small(_p(P), Rp, _p(Q), Q.stride(0), Qc or Q.shape[1], M, _p(rows_dev), _stream()), "aldm_tn_small")
 
+
+
+class TnBatch:
+    """Deferred LoRA-gradient products: collects (P, Q, rows) jobs during the backward pass and runs them in ONE
+    aldm_tn_batched launch per rank padding (Rp = 32 / 64).  The device job tables are allocated once (stable pointers for
+    hipGraph capture); under capture the launch is recorded first and `upload()` fills the tables after the capture ends."""
+    REC = 48                         # sizeof(TnJob): 3 pointers + 6 ints
+
+    def __init__(self, capacity, device):
+        self.capacity = capacity
+        self.tab = {rp: torch.zeros(capacity * self.REC, dtype=torch.uint8, device=device) for rp in (32, 64)}
+        self.jobs = {32: [], 64: []}
+        self.keep = []               # operand tensors stay referenced until the launch is recorded
+        self._packed = {}
+
+    def add(self, P, Q, rows_dev, Qc):
+        M, Rp = P.shape
+        ldq = Q.stride(0)
+        if ldq % 8 or Qc % 8 or P.data_ptr() % 16 or Q.data_ptr() % 16 or len(self.jobs[Rp]) >= self.capacity:
+            tn_small(P, Q, rows_dev, Qc=Qc)                  # odd shapes: the per-call (scalar) path
+            return
+        qt = -(-Qc // 128)
+        msplit = max(1, 24 // qt)                            # ~24 workgroups per job: the whole batch fills the GPU
+        mpb = max(64, -(-(-(-M // msplit)) // 32) * 32)
+        self.jobs[Rp].append((P.data_ptr(), Q.data_ptr(), rows_dev.data_ptr(), M, ldq, Qc, qt, mpb, qt * (-(-M // mpb))))
+        self.keep += [P, Q, rows_dev]
+
+    def _pack(self):
+        import struct
+        self._packed = {}
+        for rp, jobs in self.jobs.items():
+            if not jobs:
+                continue
+            wg0, recs = 0, []
+            for (pp, qq, rr, M, ldq, Qc, qt, mpb, nwg) in jobs:
+                recs.append(struct.pack("<qqqiiiiii", pp, qq, rr, M, ldq, Qc, qt, mpb, wg0))
+                wg0 += nwg
+            self._packed[rp] = (b"".join(recs), len(jobs), wg0)
+
+    def upload(self):
+        """Copy the packed tables to the device (outside any capture)."""
+        for rp, (blob, n, _) in self._packed.items():
+            self.tab[rp][: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+
+    def launch(self):
+        self._pack()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.upload()
+        for rp, (_, n, total) in self._packed.items():
+            check(_lib.load().aldm_tn_batched(_p(self.tab[rp]), n, total, rp, _stream()), "aldm_tn_batched")
+        self.jobs = {32: [], 64: []}
+        self.keep = []
 
 def lora_pack(jobs_dev, njobs):
     check(_lib.load().aldm_lora_pack(_p(jobs_dev), njobs, _stream()), "aldm_lora_pack")

@@ -53,9 +53,8 @@ def acc(v, g):
 
 def prior(v, like=None):
     """The gradient v already holds from its other consumers (residual / skip joins), shaped like `like`, or None.
-    Kernels that can ADD it (GEMM epilogue `res=`, norm backward `dx_into=`) take it instead of a separate add launch.
-    In-place accumulation is safe: v.g may alias a downstream tensor's gradient, but every reader of that tensor has
-    already run by the time an upstream op's backward executes (the tape runs in reverse)."""
+    Kernels that can ADD it (GEMM epilogue `res=`, norm backward `dx_add=`) take it instead of a separate add launch.  They
+    write a FRESH tensor: v.g may alias a downstream gradient that a deferred LoRA-gradient job (ops.TnBatch) still reads."""
     if v is None or not v.rg or v.g is None:
         return None
     return v.g if like is None else v.g.view(like.shape)
@@ -68,8 +67,9 @@ def put(v, g):
 
 
 class Tape:
-    def __init__(self):
+    def __init__(self, tn=None):
         self.fns = []
+        self.tn = tn                 # ops.TnBatch: LoRA-gradient products are deferred to one launch after the backward pass
 
     def record(self, fn):
         self.fns.append(fn)
@@ -137,7 +137,7 @@ def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None):
             if y.g is None:
                 return
             dx, dx2 = ops.groupnorm_bwd(x.t, y.g, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None),
-                                        need_dx2=(x2 is not None and x2.rg), dx_into=prior(x), dx2_into=prior(x2))
+                                        need_dx2=(x2 is not None and x2.rg), dx_add=prior(x), dx2_add=prior(x2))
             put(x, dx)
             put(x2, dx2)
         tape.record(bwd)
@@ -147,7 +147,7 @@ def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None):
 def t_layernorm(tape, x, gamma, beta):
     y = Var(ops.layernorm(x.t, gamma, beta), x.rg)
     if x.rg:
-        tape.record(lambda: put(x, ops.layernorm_bwd(x.t, y.g, gamma, dx_into=prior(x))) if y.g is not None else None)
+        tape.record(lambda: put(x, ops.layernorm_bwd(x.t, y.g, gamma, dx_add=prior(x))) if y.g is not None else None)
     return y
 
 
@@ -210,8 +210,12 @@ def t_lora_linear(tape, x, site, res=None):
         U = torch.empty(M, site.Rp, dtype=torch.bfloat16, device=dy.device)
         g0 = prior(x, x.t)
         put(x, ops.linear(dy, site.bwd, lora_t_out=U, splits=1, res=g0))     # dx = dy W + (dy sB) A (+ prior) ; U = dy sB
-        ops.tn_small(T, dy, site.rows_db, Qc=site.N)
-        ops.tn_small(U, x.t, site.rows_da, Qc=site.K)
+        if tape.tn is not None:
+            tape.tn.add(T, dy, site.rows_db, site.N)
+            tape.tn.add(U, x.t, site.rows_da, site.K)
+        else:
+            ops.tn_small(T, dy, site.rows_db, Qc=site.N)
+            ops.tn_small(U, x.t, site.rows_da, Qc=site.K)
     tape.record(bwd)
     return y
 
@@ -270,6 +274,7 @@ class LoraTrainer:
         self.use_graph, self.graph, self._static, self._eager_steps = use_graph, None, None, 0
         self.ac_dev = scheduler.alphas_cumprod.to(self.dev, torch.float32)
         self._build_sites()
+        self.tnb = ops.TnBatch(4 * len(self.sites) + 8, self.dev)       # <= 2 sites per attention, 2 products per site
         dp.broadcast_(self.flat.params, src=0)                  # DDP's initial parameter broadcast (C3), LoRA buffer only
 
     # ---- site construction ----
@@ -426,10 +431,11 @@ class LoraTrainer:
         tgt = ops.nchw_to_nhwc(noise, out_f32=True)
         t_dev = timesteps.to(torch.float32)
         cls = ops.f32_to_bf16(prompt_embeds)
-        tape = Tape()
+        tape = Tape(self.tnb)
         pred = self.forward(tape, x_in, t_dev, cls)
         pred.g = ops.mse_grad(pred.t, tgt, f.grads[f.n:])
         tape.backward()
+        self.tnb.launch()                                        # every dA / dB of the step: one launch (two if Rp differs)
 
     def _to_dev(self, latents, noise, timesteps, prompt_embeds):
         return (latents.to(self.dev, torch.float32).contiguous(), noise.to(self.dev, torch.float32).contiguous(),
@@ -458,6 +464,7 @@ class LoraTrainer:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
             self._fwd_bwd(*self._static)
+        self.tnb.upload()                                        # job table of the captured addresses (H2D copies cannot be captured)
         self.graph.replay()
         return f.grads[f.n:]
 

@@ -191,13 +191,13 @@ int aldm_add_noise(const float* x, const float* noise, const float* coef, int B,
  * is frozen, so only dX flows through GroupNorm / LayerNorm / GEGLU / up-sampling, and only the LoRA matrices get
  * weight gradients (aldm_tn_small).  dX of convolutions / linears is aldm_igemm with transposed weights.
  * ------------------------------------------------------------------------------------------ */
-/* `accumulate`: the tensor x (x2) feeds more than one consumer (residual / skip connections), so its gradient buffer may
-   already hold the other consumers' share: bit 0 (bit 1) makes the kernel ADD into dx (dx2) in place instead of
-   overwriting it -- the separate element-wise add launch per residual join disappears. */
+/* dx_acc (dx2_acc): the tensor x (x2) feeds more than one consumer (residual / skip connections); the gradient it already
+   received from the others is passed here and ADDED to the result -- the separate element-wise add launch per join
+   disappears.  NULL = none.  May alias dx (dx2). */
 int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
-                       float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2, int accumulate,
-                       void* stream);
-int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx, int accumulate,
+                       float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2, const void* dx_acc,
+                       const void* dx2_acc, void* stream);
+int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx, const void* dx_acc,
                        void* stream);
 /* GEGLU on the interleaved (16 value | 16 gate) projection h [M][2I]: out [M][I] = value * gelu(gate), and its backward */
 int aldm_geglu_fwd(const void* h, long long M, int I, void* out, void* stream);
@@ -208,6 +208,12 @@ int aldm_upsample_nearest_bwd(const void* dy, int B, int IH, int IW, int OH, int
    device table rows_dev[p] = {float* dst; int qlo, qhi, qstride; float scale}: dst[(q-qlo)*qstride] += scale*value for
    qlo <= q < qhi (fp32 atomics into the flat LoRA gradient buffer). */
 int aldm_tn_small(const void* P, int Rp, const void* Q, int ldq, int Qc, int M, const void* rows_dev, void* stream);
+/* The same products for MANY (P, Q) pairs in one launch (the trainer defers the 2 x 64 LoRA-gradient products of a step to the
+   end of the backward pass).  jobs_dev: device array of njobs records
+     { const void* P; const void* Q; const void* rows; int M, ldq, Qc, qt, mpb, wg0; }   (48 bytes)
+   with qt = ceil(Qc / 128) column blocks, mpb = rows per workgroup (multiple of 32), wg0 = first workgroup id of the job
+   (ascending; total_wgs = sum of qt * ceil(M / mpb)); every P has Rp columns; ldq, Qc multiples of 8, 16-byte aligned. */
+int aldm_tn_batched(const void* jobs_dev, int njobs, int total_wgs, int Rp, void* stream);
 /* jobs_dev[i] = {const float* src; bf16* dst; int rows, cols, src_ld, dst_ld, transpose; float scale}: one launch converts
    the flat fp32 LoRA parameters into every packed bf16 operand of the fused GEMMs. */
 int aldm_lora_pack(const void* jobs_dev, int njobs, void* stream);

@@ -52,15 +52,15 @@ def test_groupnorm_bwd(ops, B, HW, C1, C2, groups, act):
     close(nchw(dx), x.grad[:, :C1])
     if C2:
         close(nchw(dx2), x.grad[:, C1:])
-    # in-place accumulation into gradients the tensors already hold (residual / skip joins)
+    # accumulation of gradients the tensors already hold (residual / skip joins), out of place
     p1 = bf(torch.randn(B, C1, H, W, generator=g))
     p2 = bf(torch.randn(B, C2, H, W, generator=g)) if C2 else None
     b1, b2 = nhwc(p1), (nhwc(p2) if C2 else None)
-    r1, r2 = ops.groupnorm_bwd(x1, nhwc(dy), gm.to(DEV), bt.to(DEV), groups, 1e-5, act, x2=x2, dx_into=b1, dx2_into=b2)
-    assert r1.data_ptr() == b1.data_ptr()
+    keep1 = b1.clone()
+    r1, r2 = ops.groupnorm_bwd(x1, nhwc(dy), gm.to(DEV), bt.to(DEV), groups, 1e-5, act, x2=x2, dx_add=b1, dx2_add=b2)
+    assert r1.data_ptr() != b1.data_ptr() and torch.equal(b1, keep1)          # the prior gradient is not modified
     close(nchw(r1), x.grad[:, :C1] + p1)
     if C2:
-        assert r2.data_ptr() == b2.data_ptr()
         close(nchw(r2), x.grad[:, C1:] + p2)
 
 
@@ -75,8 +75,8 @@ def test_layernorm_and_geglu_bwd(ops):
         close(dx, x.grad)
         prev = bf(torch.randn(50, Cc, generator=g))
         buf = prev.to(torch.bfloat16).to(DEV)
-        out = ops.layernorm_bwd(x.detach().to(torch.bfloat16).to(DEV), dy.to(torch.bfloat16).to(DEV), gm.to(DEV), dx_into=buf)
-        assert out.data_ptr() == buf.data_ptr()
+        out = ops.layernorm_bwd(x.detach().to(torch.bfloat16).to(DEV), dy.to(torch.bfloat16).to(DEV), gm.to(DEV), dx_add=buf)
+        assert out.data_ptr() != buf.data_ptr()
         close(out, x.grad + prev)
     # GEGLU on the interleaved layout
     M, I = 40, 64
@@ -224,3 +224,29 @@ def test_transpose_tokens_fast_and_generic_paths(ops, B, N, C, ld):
     want = torch.zeros(B, C, npad, dtype=torch.bfloat16)
     want[:, :, :N] = full[:, :C].view(B, N, C).transpose(1, 2)
     assert torch.equal(got, want)
+
+
+def test_tn_batched_many_jobs_one_launch(ops):
+    """ops.TnBatch: several (P, Q) products of different shapes and rank paddings in one launch per Rp == the per-call path."""
+    import struct
+    g = torch.Generator().manual_seed(77)
+    shapes = [(1024, 32, 256, 256), (300, 32, 96, 288), (64, 64, 1920, 1920), (2048, 32, 384, 384), (515, 64, 136, 136), (97, 32, 36, 44)]
+    tb = ops.TnBatch(16, DEV)
+    outs, wants, keep = [], [], []
+    for (M, Rp, Qc, ldq) in shapes:
+        P = bf(torch.randn(M, Rp, generator=g))
+        Q = bf(torch.randn(M, ldq, generator=g))
+        flat = torch.zeros(Rp * Qc, device=DEV)
+        rows = torch.zeros(Rp, 24, dtype=torch.uint8)
+        for p_ in range(Rp):
+            rows[p_] = torch.tensor(list(struct.pack("<qiiif", flat.data_ptr() + 4 * p_ * Qc, 0, Qc, 1, 1.0)), dtype=torch.uint8)
+        Pd, Qd, rd = P.to(torch.bfloat16).to(DEV), Q.to(torch.bfloat16).to(DEV), rows.to(DEV)
+        tb.add(Pd, Qd[:, :Qc] if ldq != Qc else Qd, rd, Qc)          # (97, 32, 36, 44): ldq % 8 != 0 -> immediate scalar path
+        keep.append((Pd, Qd, rd))
+        outs.append(flat)
+        wants.append(P.t() @ Q[:, :Qc])
+    assert len(tb.jobs[32]) == 3 and len(tb.jobs[64]) == 2
+    tb.launch()
+    assert not tb.jobs[32] and not tb.jobs[64] and not tb.keep
+    for flat, want in zip(outs, wants):
+        close(flat.cpu().view(want.shape), want, rtol=1e-3, atol=2e-3 * float(want.abs().max()))
