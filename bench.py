@@ -57,14 +57,21 @@ def kernel_profile(engine, fine=False):
     ops.PROFILE = []
     ops.sleep_us(60000)          # queue the whole step behind a 60 ms sleep: event pairs then time kernels, not host gaps
     engine._one_step()
+    empty = []                   # the event pair itself costs time on the stream: calibrate it with empty pairs in the same queue
+    for _ in range(64):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        e.record()
+        empty.append((s, e))
     torch.cuda.synchronize()
+    pair_ms = sorted(s.elapsed_time(e) for s, e in empty)[len(empty) // 2]
     rows, ops.PROFILE = ops.PROFILE, None
     agg = {}
     for label, flops, nbytes, s, e in rows:
         if not fine:
             label = label.split("|")[0]
         a = agg.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        a["ms"] += s.elapsed_time(e)
+        a["ms"] += max(s.elapsed_time(e) - pair_ms, 1e-4)
         a["flops"] += flops
         a["bytes"] += nbytes
         a["launches"] += 1
