@@ -169,6 +169,12 @@ def pack_resnet(r: ResnetBlock2D):
         groups=r.groups, eps=r.eps, cout=r.cout, temb_off=0)
 
 
+# The LayerNorm fold trades a ~3-5 us LayerNorm launch for in-kernel row statistics (extra LDS reads per K-tile) and a longer
+# epilogue.  Measured in a replayed graph (tools/bench_qkv_graph.py): it wins at C = 640 (N = 64 tokens: -0.7 us on the QKV GEMM,
+# -1.5 us on the GEGLU GEMM), is a wash for the C = 256 QKV GEMM and LOSES 2.7-3.5 us on the C = 384 QKV / C = 256 GEGLU GEMMs.
+LN_FOLD_MIN_C = 512
+
+
 def pack_attention(a: Attention, ln=None):
     """ln = (gamma, beta) of the LayerNorm feeding this attention: folded into the fused QKV GEMM when the LDS-DMA
     path can take it (C % 64 == 0); the caller then passes the RAW hidden state."""
@@ -180,7 +186,7 @@ def pack_attention(a: Attention, ln=None):
     bias = None
     if bq is not None:
         bias = torch.cat([bq, bk, bv])
-    fold = ln is not None and c % 64 == 0
+    fold = ln is not None and c % 64 == 0 and c >= LN_FOLD_MIN_C
     qkv = ops.pack_linear_ln(torch.cat([wq, wk, wv]), bias, ln[0], ln[1]) if fold else ops.pack_linear(torch.cat([wq, wk, wv]), bias)
     ops.attach_lora(qkv, [None if l is None else (i * c, c, l[0], l[1], l[2]) for i, l in enumerate((lq, lk, lv))])
     out = ops.pack_linear(wo, bo)
@@ -197,7 +203,7 @@ def pack_transformer(t: Transformer2DModel):
         attn1=pack_attention(blk.attn1, (blk.norm1.weight, blk.norm1.bias)),
         attn2=pack_attention(blk.attn2, (blk.norm2.weight, blk.norm2.bias)),
         ff1=(ops.pack_linear_ln(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, blk.norm3.weight, blk.norm3.bias, geglu=True)
-             if t.channels % 64 == 0 else ops.pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias)),
+             if (t.channels % 64 == 0 and t.channels >= LN_FOLD_MIN_C) else ops.pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias)),
         ff2=ops.pack_linear(blk.ff.net[2].weight, blk.ff.net[2].bias))
 
 
