@@ -274,7 +274,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       }
     }
   };
-  auto phaseB = [&](int it0) {                               // arithmetic + stores
+  // ACT = std::true_type only when the launch carries an activation: the SiLU / tanh / erf-GELU code (thousands of
+  // instructions once inlined per value) then stays out of the instruction stream of every other launch -- before this
+  // split the epilogue was 14.5k instructions and its instruction-cache misses cost more than the K loop of the small GEMMs.
+  auto phaseB = [&](auto ACT, int it0) {                     // arithmetic + stores
+    constexpr bool kAct = decltype(ACT)::value;
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       if (!ok[u]) continue;
@@ -290,9 +294,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { v[q] += colb[q] + rb0[u][q]; v[4 + q] += colb[4 + q] + rb1[u][q]; }
-      if (p.out_act) {
+      if constexpr (kAct) {
+        if (p.out_act) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.out_act, p.out_slope);
+          for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.out_act, p.out_slope);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = (v[q] + (float)r1[u][q]) * p.alpha + (float)r2[u][q];
@@ -300,11 +306,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         bf16* o2 = p.out2 + rowo[u] + n;
         bf16x8 t;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = (bf16)apply_act(v[q], p.post_act, p.post_slope);
+        for (int q = 0; q < 8; ++q) {
+          if constexpr (kAct) t[q] = (bf16)apply_act(v[q], p.post_act, p.post_slope);
+          else t[q] = (bf16)v[q];
+        }
         if (vec) *reinterpret_cast<bf16x8*>(o2) = t;
         else
           for (int q = 0; q < 8; ++q) if (n + q < p.N) o2[q] = t[q];
-      } else if (p.post_act) {
+      } else if (kAct && p.post_act) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], p.post_act, p.post_slope);
       }
@@ -425,11 +434,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   }
   // Standard path, second half: the first CH rows were prefetched before the LDS transposition (see the top of this function)
   if (n >= p.N) return;
-  phaseB(0);
+  if (p.out_act | p.post_act) {
+    phaseB(std::true_type{}, 0);
 #pragma unroll
-  for (int it0 = CH; it0 < ITERS; it0 += CH) {
-    phaseA(it0);
-    phaseB(it0);
+    for (int it0 = CH; it0 < ITERS; it0 += CH) {
+      phaseA(it0);
+      phaseB(std::true_type{}, it0);
+    }
+  } else {
+    phaseB(std::false_type{}, 0);
+#pragma unroll
+    for (int it0 = CH; it0 < ITERS; it0 += CH) {
+      phaseA(it0);
+      phaseB(std::false_type{}, it0);
+    }
   }
 }
 
