@@ -337,10 +337,26 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
   };
   if (std_path && n < p.N) {
+    // column vectors: two 16-byte loads each when the 8 columns are in range (per-element predicated loads compile to eight
+    // exec-masked blocks whose loads complete one after the other: measured 3.6 us of the epilogue on the 64x64 tile)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      colb[q] = (p.bias && n + q < p.N) ? p.bias[n + q] : 0.f;
-      lns[q] = (lnst && n + q < p.N) ? p.ln_s[n + q] : 0.f;
+    for (int q = 0; q < 8; ++q) colb[q] = lns[q] = 0.f;
+    if (n + 7 < p.N) {
+      if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { colb[q] = b0[q]; colb[4 + q] = b1[q]; }
+      }
+      if (lnst) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.ln_s + n), s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lns[q] = s0[q]; lns[4 + q] = s1[q]; }
+      }
+    } else {
+      for (int q = 0; q < 8; ++q) {
+        if (p.bias && n + q < p.N) colb[q] = p.bias[n + q];
+        if (lnst && n + q < p.N) lns[q] = p.ln_s[n + q];
+      }
     }
     phaseA(0);
   }
