@@ -213,7 +213,10 @@ struct EpiCfg {
   static constexpr int BYTES = (BM * LD > BN * LDT ? BM * LD : BN * LDT) * 4;
 };
 
-template <int BM, int BN, int MI, int NI, bool VT, int NT = 256>
+// LEAN = true: the launch is known (host-checked) to take the standard path without an activation -- no V^T tile, no split-K,
+// no GEGLU -- and every other path is compiled out: the kernel's instruction footprint shrinks from ~16k to a few thousand
+// instructions, which is what its instruction-cache behaviour needs.
+template <int BM, int BN, int MI, int NI, bool VT, int NT = 256, bool LEAN = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], char* smem, bool vt_wg, int m0,
                                                int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid,
                                                const float* lnst = nullptr) {
@@ -229,7 +232,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
   static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
   const int r0 = tid / GPR, c = (tid % GPR) * 8, n = n0 + c;
-  const bool std_path = !(VT && vt_wg) && p.splits <= 1 && !p.geglu;
+  const bool std_path = LEAN || (!(VT && vt_wg) && p.splits <= 1 && !p.geglu);
   const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
   const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
   float colb[8], lns[8];
@@ -362,7 +365,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   }
 
   __syncthreads();                                           // every wave is done with the K-loop images
-  if (VT && vt_wg) {
+  if (!LEAN && VT && vt_wg) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -377,6 +380,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   }
   __syncthreads();
 
+  if constexpr (!LEAN) {
   if (VT && vt_wg) {
     // rows of the image are channels n, columns are pixels: vt[b][n - col0][pix .. pix+7]
     for (int g = tid; g < BN * (BM / 8); g += NT) {
@@ -448,9 +452,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
     return;
   }
+  }
   // Standard path, second half: the first CH rows were prefetched before the LDS transposition (see the top of this function)
   if (n >= p.N) return;
-  if (p.out_act | p.post_act) {
+  if (!LEAN && (p.out_act | p.post_act)) {
     phaseB(std::true_type{}, 0);
 #pragma unroll
     for (int it0 = CH; it0 < ITERS; it0 += CH) {
@@ -708,7 +713,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, bool LEAN = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef ALDM_DIAG
@@ -1011,7 +1016,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
       else mma_step(std::false_type{}, smem, LBs, ks, false);
     }
   }
-  igemm_epilogue<BM, BN, MI, NI, VT, NT>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
+  igemm_epilogue<BM, BN, MI, NI, VT, NT, LEAN>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
 #ifdef ALDM_DIAG
   if (p.diag && lane == 0) {
     unsigned long long dg_t_end; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_end) :: "memory");
@@ -1062,7 +1067,7 @@ static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev
   }
 }
 
-template <int BM, int BN, int WM, int WN, int RP, bool VT, int S>
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, bool LEAN = false>
 int launch_cfg(const IgemmDev& d, hipStream_t st) {
   // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
   constexpr size_t lds_loop = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
@@ -1070,7 +1075,7 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   static bool attr_done = false;   // one-time, idempotent; races are benign
   void (*kern)(const IgemmDev);
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
-  else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S>;
+  else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S, LEAN>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { aldm_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -1093,6 +1098,14 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
     if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S>(d, st);
     if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S>(d, st);
     return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
+  }
+  if constexpr (S != 0) {
+    // the common case -- standard epilogue, no activation -- runs the LEAN instantiation (nothing else compiled in)
+    if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE) {
+      if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S, true>(d, st);
+      if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S, true>(d, st);
+      return launch_cfg<BM, BN, WM, WN, 64, false, S, true>(d, st);
+    }
   }
   if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S>(d, st);
   if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S>(d, st);

@@ -23,7 +23,7 @@
 
 namespace aldm_igemm_detail {
 
-template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S>
+template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, bool LEAN>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WM * WN == 8, "8 waves");
@@ -183,17 +183,17 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   // rows of this tile past the bottom of the image alias the next image's first rows: cut M for the epilogue's bound checks
   IgemmDev q = p;
   q.M = min(p.M, min(m0 + BM, (img + 1) * p.OHW));
-  igemm_epilogue<BM, BN, MI, NI, false, NT>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
+  igemm_epilogue<BM, BN, MI, NI, false, NT, LEAN>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int HP, int S>
-int launch_halo(const IgemmDev& d, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int HP, int S, bool LEAN>
+int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128;
   constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
-  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S>;
+  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, LEAN>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { aldm_set_error("igemm_halo: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -211,6 +211,12 @@ int launch_halo(const IgemmDev& d, hipStream_t st) {
   dim3 grid(d.B * tpi * dd.tiles_n, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dd);
   return aldm_launch_status("igemm_halo");
+}
+
+template <int BM, int BN, int WM, int WN, int HP, int S>
+int launch_halo(const IgemmDev& d, hipStream_t st) {
+  if (d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE) return launch_halo_v<BM, BN, WM, WN, HP, S, true>(d, st);
+  return launch_halo_v<BM, BN, WM, WN, HP, S, false>(d, st);
 }
 
 }  // namespace aldm_igemm_detail
