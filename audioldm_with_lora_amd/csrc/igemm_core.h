@@ -222,6 +222,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
                                                const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
   float* Cs = reinterpret_cast<float*>(smem);
+  if constexpr (LEAN) lnst = nullptr;
 
   // Standard path (no V^T tile, no split-K, no GEGLU).  A thread keeps ONE 8-column group (NT % (BN/8) == 0) and walks down
   // the rows, so the bias / LayerNorm column vectors are loaded once.  Rows are handled CH at a time in two phases: phase A
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   // tensor in HBM.
   constexpr int TPR = NT / BM;                       // threads per tile row
   constexpr int CPT = 8 / TPR;                            // 16-byte chunks of a 64-wide K-tile per thread
-  const bool lnf = p.ln_s != nullptr;
+  const bool lnf = !LEAN && p.ln_s != nullptr;           // LEAN launches never carry a folded LayerNorm (host-checked)
   const int ln_row = tid / TPR, ln_c0 = (tid % TPR) * CPT;
   float ln_sum = 0.f, ln_sq = 0.f;
   auto ln_accum = [&](const char* As) {
@@ -1101,7 +1102,7 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
   }
   if constexpr (S != 0) {
     // the common case -- standard epilogue, no activation -- runs the LEAN instantiation (nothing else compiled in)
-    if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE) {
+    if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE && !d.ln_s) {
       if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S, true>(d, st);
       if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S, true>(d, st);
       return launch_cfg<BM, BN, WM, WN, 64, false, S, true>(d, st);
