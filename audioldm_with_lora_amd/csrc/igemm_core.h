@@ -222,7 +222,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
                                                const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
   float* Cs = reinterpret_cast<float*>(smem);
-  if constexpr (LEAN) lnst = nullptr;
+  if constexpr (LEAN && !VT) lnst = nullptr;               // LEAN keeps the V^T tile and the LayerNorm fold only in VT kernels
 
   // Standard path (no V^T tile, no split-K, no GEGLU).  A thread keeps ONE 8-column group (NT % (BN/8) == 0) and walks down
   // the rows, so the bias / LayerNorm column vectors are loaded once.  Rows are handled CH at a time in two phases: phase A
@@ -233,7 +233,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
   static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
   const int r0 = tid / GPR, c = (tid % GPR) * 8, n = n0 + c;
-  const bool std_path = LEAN || (!(VT && vt_wg) && p.splits <= 1 && !p.geglu);
+  const bool std_path = !(VT && vt_wg) && (LEAN || (p.splits <= 1 && !p.geglu));
   const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
   const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
   float colb[8], lns[8];
@@ -366,7 +366,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   }
 
   __syncthreads();                                           // every wave is done with the K-loop images
-  if (!LEAN && VT && vt_wg) {
+  if (VT && vt_wg) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -381,7 +381,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   }
   __syncthreads();
 
-  if constexpr (!LEAN) {
   if (VT && vt_wg) {
     // rows of the image are channels n, columns are pixels: vt[b][n - col0][pix .. pix+7]
     for (int g = tid; g < BN * (BM / 8); g += NT) {
@@ -414,6 +413,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
     return;
   }
+  if constexpr (!LEAN) {
   if (p.splits > 1) {
     for (int g = tid; g < BM * (BN / 8); g += NT) {
       const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   // tensor in HBM.
   constexpr int TPR = NT / BM;                       // threads per tile row
   constexpr int CPT = 8 / TPR;                            // 16-byte chunks of a 64-wide K-tile per thread
-  const bool lnf = !LEAN && p.ln_s != nullptr;           // LEAN launches never carry a folded LayerNorm (host-checked)
+  const bool lnf = (!LEAN || VT) && p.ln_s != nullptr;   // LEAN non-V^T launches never carry a folded LayerNorm (host-checked)
   const int ln_row = tid / TPR, ln_c0 = (tid % TPR) * CPT;
   float ln_sum = 0.f, ln_sq = 0.f;
   auto ln_accum = [&](const char* As) {
@@ -1096,6 +1096,13 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int S>
 int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
   if (vt) {
+    if constexpr (S != 0) {
+      if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE) {   // LEAN V^T: no split / GEGLU / act code
+        if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S, true>(d, st);
+        if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S, true>(d, st);
+        return launch_cfg<BM, BN, WM, WN, 64, true, S, true>(d, st);
+      }
+    }
     if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S>(d, st);
     if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S>(d, st);
     return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
