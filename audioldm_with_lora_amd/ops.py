@@ -486,7 +486,7 @@ def layernorm(x2d, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(qk, vt, B, N, H, d, out=None, kv_len=None):
+def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False):
     """qk [B*N, 2C] (Q | K), vt [B, C, Npad]; returns [B*N, C].  kv_len: optional int32 [B] valid-key counts
     (right-padded batches)."""
     _require_gpu(qk)
@@ -501,6 +501,11 @@ def attention(qk, vt, B, N, H, d, out=None, kv_len=None):
         check(_launch(f"attention_varlen_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention_varlen(
             q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
             _p(kv_len), _p(out), Cc, _stream())), "aldm_attention_varlen")
+        return out
+    if fp8:                                                   # config 5: e4m3 Q / K / V / P operands
+        check(_launch(f"attention_fp8_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention_fp8(
+            q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
+            _p(out), Cc, _stream())), "aldm_attention_fp8")
         return out
     check(_launch(f"attention_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention(
         q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),

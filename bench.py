@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the short LoRA-training measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--fine", action="store_true", help="print the per-kernel-per-shape table to stderr")
+    ap.add_argument("--fp8-attention", action="store_true", help="BASELINE config 5: fp8 (e4m3) Q/K/V/P attention operands")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +240,7 @@ def main():
 
     H, W, NSTEPS, G = 250, 16, 200, 2.5
     unet, _ = build_unet(args.rank)
+    unet.attention_fp8 = args.fp8_attention
     eng = DenoiseEngine(unet, DDIMScheduler(), args.batch, H, W, NSTEPS, G, use_graph=not args.no_graph, chains=args.chains)
     lat, pe, ne = synth_inputs(args.batch, H, W, seed_off=100 * rank)
     eng.set_condition(pe, ne)
@@ -304,7 +306,7 @@ def main():
             "metric": "unet_denoise_steps_per_sec", "value": round(world * args.steps / dt, 3), "unit": "denoise_steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if not args.fp8_attention else "bf16 (fp8 e4m3 attention operands)", "data": "synthetic",
             "config": {"workload": "audioldm-s-full-v2 UNet + rank-%d LoRA (q,k,v,out), DDIM 200-step schedule, "
                                    "batch %d x 10 s clips (latent 250x16), CFG 2.5 (UNet batch %d), bf16" % (args.rank, args.batch, 2 * args.batch),
                        "per_gpu_batch": args.batch, "parallelism": f"prompt-sharded x{world}", "hip_graph": not args.no_graph, "graph_chains": eng.chains,

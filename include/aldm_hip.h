@@ -139,6 +139,12 @@ int aldm_attention_varlen(const void* q, int ldq, const void* k, int ldk, const 
                           long long vt_batch_stride, int B, int N, int H, int d, float scale, const int* kv_len,
                           void* out, int out_ld, void* stream);
 
+/* BASELINE config 5: the same core with fp8 (OCP e4m3) Q / K / V / P MFMA operands and fp32 accumulation.  Inputs and output
+   stay bf16 (converted while staged); P is scaled by 2^8 internally.  Operand-precision variant, not a faster one. */
+int aldm_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                       long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
+                       void* stream);
+
 int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                        long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                        float* lse, void* stream);

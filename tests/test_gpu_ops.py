@@ -313,3 +313,27 @@ def test_conv3x3_eight_wave_tile(ops, ring):
     want = F.conv2d(torch.cat([x, x2], 1), w, b, padding=1) + r
     y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=6, ring=ring)
     close(to_nchw(y), want)
+
+
+@pytest.mark.parametrize("d,H,N,B", [(32, 8, 1000, 2), (48, 8, 252, 2), (80, 8, 64, 3), (16, 4, 40, 2)])
+def test_attention_fp8_operands(ops, d, H, N, B):
+    """BASELINE config 5: e4m3 Q/K/V/P MFMA operands, fp32 accumulation.  Compared (a) with the fp32 reference at an fp8-level
+    tolerance and (b) with a reference whose Q/K/V are rounded to e4m3 first (isolates the kernel from the input rounding)."""
+    g = torch.Generator().manual_seed(d + N)
+    C = H * d
+    q, k, v = (bf(torch.randn(B, N, C, generator=g)) for _ in range(3))
+    qk = torch.cat([q, k], 2).reshape(B * N, 2 * C).to(torch.bfloat16).to(DEV)
+    npad = (N + 7) // 8 * 8
+    vt = torch.zeros(B, C, npad, dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :N] = v.transpose(1, 2).to(torch.bfloat16).to(DEV)
+    got = ops.attention(qk, vt, B, N, H, d, fp8=True).float().cpu().view(B, N, C)
+    sp = lambda t: t.view(B, N, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, N, C)
+    q8, k8, v8 = (t.to(torch.float8_e4m3fn).float() for t in (q, k, v))
+    ref8 = F.scaled_dot_product_attention(sp(q8), sp(k8), sp(v8)).transpose(1, 2).reshape(B, N, C)
+    rel = lambda a, b_: float((a - b_).norm() / b_.norm())
+    assert torch.isfinite(got).all()
+    assert rel(got, ref8) < 4e-2, rel(got, ref8)          # P in e4m3 (3 mantissa bits), everything else exact
+    assert rel(got, ref) < 8e-2, rel(got, ref)
+    bf16_out = ops.attention(qk, vt, B, N, H, d).float().cpu().view(B, N, C)
+    assert rel(bf16_out, ref) < rel(got, ref)             # sanity: the bf16 kernel is the more accurate one
