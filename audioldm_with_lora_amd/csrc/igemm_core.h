@@ -123,15 +123,23 @@ __device__ __forceinline__ void finish_store4(const IgemmDev& p, int m, int n, i
 }
 
 __device__ __forceinline__ void add_bias4(const IgemmDev& p, int m, int n, float* v) {
+  // n % 4 == 0 and N % 4 == 0 on this path (split-K reduce): whole 16-byte vectors, never per-element predicated loads
   if (p.bias) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += p.bias[n + j];
+    for (int j = 0; j < 4; ++j) v[j] += b[j];
   }
   if (p.rowbias) {
-    const int b = m / p.OHW;
-    const float* rb = p.rowbias + (long long)b * p.rowbias_ld;
+    const int bi = fdiv(m, p.fd_ohw);
+    const float* rb = p.rowbias + (long long)bi * p.rowbias_ld + n;
+    if ((p.rowbias_ld & 3) == 0) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(rb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += rb[n + j];
+      for (int j = 0; j < 4; ++j) v[j] += r[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += rb[j];
+    }
   }
 }
 
@@ -1057,9 +1065,20 @@ static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev
     for (int q = 0; q < 4; ++q) val[q] *= gelu_erf_f(gate[q]);
     finish_store4(p, m, n, ncols, val);
   } else {
+    // four partials per trip: the loads of a trip are in flight together (a one-load-per-trip loop pays one memory round
+    // trip per split); summation stays in split order
     float v[4] = {0, 0, 0, 0};
-    for (int s = 0; s < p.splits; ++s) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws + ((long long)s * p.M + m) * p.N + n);
+    const float* w0 = p.ws + (long long)m * p.N + n;
+    const long long sstride = (long long)p.M * p.N;
+    int s = 0;
+    for (; s + 4 <= p.splits; s += 4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(w0 + (s + 0) * sstride), a1 = *reinterpret_cast<const f32x4*>(w0 + (s + 1) * sstride);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(w0 + (s + 2) * sstride), a3 = *reinterpret_cast<const f32x4*>(w0 + (s + 3) * sstride);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (((v[q] + a0[q]) + a1[q]) + a2[q]) + a3[q];
+    }
+    for (; s < p.splits; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + s * sstride);
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] += a[q];
     }
