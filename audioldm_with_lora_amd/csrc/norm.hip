@@ -150,49 +150,61 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
   }
 }
 
-// LayerNorm: one wave per row, 16-byte chunks, C <= 64*8*MAXC.
+// LayerNorm: LPR lanes per row (a full wave, or half a wave when the row has <= 32 16-byte chunks, i.e. C <= 256 -- the
+// widest level of the UNet -- so that no lane idles), 16-byte chunks, C <= LPR*8*MAXC.
 constexpr int LN_MAXC = 4;  // chunks per lane -> C <= 2048
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int M, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         bf16* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= M) return;
+  constexpr int RPW = 64 / LPR;                          // rows per wave
+  const int lane = threadIdx.x & (LPR - 1);
+  const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
+  const bool live = row < M;                             // keep every lane in the shuffles
   const int nch = C >> 3;
-  const bf16* xr = x + (long long)row * C;
+  const bf16* xr = x + (long long)(live ? row : 0) * C;
   bf16x8 v[LN_MAXC];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     if (ch < nch) {
       v[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += (float)v[i][k];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+  const float mean = row_sum<LPR>(s) / (float)C;
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     if (ch < nch) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { const float d = (float)v[i][k] - mean; ss += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  const float rstd = rsqrtf(row_sum<LPR>(ss) / (float)C + eps);
+  if (!live) return;
   bf16* yr = y + (long long)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     if (ch < nch) {
       bf16x8 o;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int c = ch * 8 + k;
-        o[k] = (bf16)(((float)v[i][k] - mean) * rstd * gamma[c] + beta[c]);
+      for (int k = 0; k < 4; ++k) {
+        o[k] = (bf16)(((float)v[i][k] - mean) * rstd * g0[k] + b0[k]);
+        o[4 + k] = (bf16)(((float)v[i][4 + k] - mean) * rstd * g1[k] + b1[k]);
       }
       *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
     }
@@ -299,8 +311,12 @@ extern "C" int aldm_layernorm(const void* x, int M, int C, const float* gamma, c
                               void* stream) {
   ALDM_CHECK_ARG(x && y && gamma && beta && M > 0, "layernorm: null pointer / bad M");
   ALDM_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "layernorm: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXC);
-  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, M, C, gamma,
-                     beta, eps, (bf16*)y);
+  if (C <= 256)
+    hipLaunchKernelGGL(layernorm_kernel<32>, dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, M, C, gamma,
+                       beta, eps, (bf16*)y);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<64>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, M, C, gamma,
+                       beta, eps, (bf16*)y);
   return aldm_launch_status("layernorm");
 }
 
