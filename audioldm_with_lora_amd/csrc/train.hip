@@ -137,62 +137,75 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
 }
 
 constexpr int LN_MAXC = 4;
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// LPR lanes per row: a full wave, or half a wave for rows of <= 32 16-byte chunks (C <= 256), as in norm.hip
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int M,
                                                             int C, const float* __restrict__ gamma, float eps,
                                                             bf16* __restrict__ dx, const bf16* dx_acc) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= M) return;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & (LPR - 1);
+  const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
+  const bool live = row < M;                       // every lane stays in the shuffles
   const int nch = C >> 3;
-  const bf16* xr = x + (long long)row * C;
-  const bf16* dr = dy + (long long)row * C;
+  const bf16* xr = x + (long long)(live ? row : 0) * C;
+  const bf16* dr = dy + (long long)(live ? row : 0) * C;
   bf16x8 v[LN_MAXC], d[LN_MAXC];
+  float gm[LN_MAXC][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     if (ch < nch) {
       v[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
       d[i] = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { gm[i][k] = g0[k]; gm[i][4 + k] = g1[k]; }
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += (float)v[i][k];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+  const float mean = row_sum<LPR>(s) / (float)C;
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i)
-    if (lane + 64 * i < nch) {
+    if (lane + LPR * i < nch) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { const float e = (float)v[i][k] - mean; ss += e * e; }
     }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  const float rstd = rsqrtf(row_sum<LPR>(ss) / (float)C + eps);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
+    if (lane + LPR * i < nch) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = ((float)v[i][k] - mean) * rstd;
-        const float gd = (float)d[i][k] * gamma[ch * 8 + k];
+        const float gd = (float)d[i][k] * gm[i][k];
         s1 += gd;
         s2 += gd * xh;
       }
     }
   }
-  s1 = wave_sum(s1) / (float)C;
-  s2 = wave_sum(s2) / (float)C;
+  s1 = row_sum<LPR>(s1) / (float)C;
+  s2 = row_sum<LPR>(s2) / (float)C;
+  if (!live) return;
   bf16* o = dx + (long long)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     if (ch < nch) {
       bf16x8 r;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = ((float)v[i][k] - mean) * rstd;
-        r[k] = (bf16)(rstd * ((float)d[i][k] * gamma[ch * 8 + k] - s1 - xh * s2));
+        r[k] = (bf16)(rstd * ((float)d[i][k] * gm[i][k] - s1 - xh * s2));
       }
       if (dx_acc) {                            // the residual stream's gradient from its other consumers (may alias dx)
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(dx_acc + (long long)row * C + ch * 8);
@@ -544,8 +557,12 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
 extern "C" int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx,
                                   const void* dx_acc, void* stream) {
   ALDM_CHECK_ARG(x && dy && dx && gamma && M > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "layernorm_bwd: bad args");
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                     (const bf16*)dy, M, C, gamma, eps, (bf16*)dx, (const bf16*)dx_acc);
+  if (C <= 256)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)dy, M, C, gamma, eps, (bf16*)dx, (const bf16*)dx_acc);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<64>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)dy, M, C, gamma, eps, (bf16*)dx, (const bf16*)dx_acc);
   return aldm_launch_status("layernorm_bwd");
 }
 
