@@ -91,7 +91,7 @@ def traffic_from_profile(label):
     bm, bn, rp, vt = m.group(1), m.group(2), m.group(3), "true" if m.group(4) else "false"
     tot = n = 0
     for k, v in prof.items():       # every ring depth / wave count of the tile family (split-K launches share the kernel)
-        km = re.match(r"igemm_pipe_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\w+), (\d+)>", k)
+        km = re.match(r"igemm_pipe_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\w+), (\d+)(?:, \w+)?>", k)
         if km and (km.group(1), km.group(2), km.group(3), km.group(4)) == (bm, bn, rp, vt):
             tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
             n += v["launches_sampled"]
