@@ -224,11 +224,13 @@ struct EpiCfg {
 // LEAN = true: the launch is known (host-checked) to take the standard path without an activation -- no V^T tile, no split-K,
 // no GEGLU -- and every other path is compiled out: the kernel's instruction footprint shrinks from ~16k to a few thousand
 // instructions, which is what its instruction-cache behaviour needs.
-template <int BM, int BN, int MI, int NI, bool VT, int NT = 256, bool LEAN = false>
+// EPI = 2 (GEGLU launches without residual / activation / second output): only the GEGLU path with a plain bf16 store.
+template <int BM, int BN, int MI, int NI, bool VT, int NT = 256, int EPI = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[MI][NI], char* smem, bool vt_wg, int m0,
                                                int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid,
                                                const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
+  constexpr bool LEAN = EPI == 1, GLEAN = EPI == 2;
   float* Cs = reinterpret_cast<float*>(smem);
   if constexpr (LEAN && !VT) lnst = nullptr;               // LEAN keeps the V^T tile and the LayerNorm fold only in VT kernels
 
@@ -241,7 +243,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
   static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
   const int r0 = tid / GPR, c = (tid % GPR) * 8, n = n0 + c;
-  const bool std_path = !(VT && vt_wg) && (LEAN || (p.splits <= 1 && !p.geglu));
+  const bool std_path = !GLEAN && !(VT && vt_wg) && (LEAN || (p.splits <= 1 && !p.geglu));
   const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
   const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
   float colb[8], lns[8];
@@ -422,7 +424,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     return;
   }
   if constexpr (!LEAN) {
-  if (p.splits > 1) {
+  if (!GLEAN && p.splits > 1) {
     for (int g = tid; g < BM * (BN / 8); g += NT) {
       const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
       const int m = m0 + r, n = n0 + c;
@@ -438,7 +440,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
     return;
   }
-  if (p.geglu) {
+  if (GLEAN || p.geglu) {
     // image columns come in blocks of (16 value | 16 gate); 8 output columns = 8 values and their 8 gates
     for (int g = tid; g < BM * (BN / 16); g += NT) {
       const int r = g / (BN / 16), jo = (g - r * (BN / 16)) * 8;        // jo: output column inside the tile
@@ -457,7 +459,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         if (p.bias) { val += p.bias[nv + q]; gate += p.bias[nv + 16 + q]; }
         v[q] = val * gelu_erf_f(gate);
       }
-      epi8(p, m, (n0 >> 1) + jo, p.N >> 1, v);
+      if constexpr (GLEAN) {
+        // host-checked: bf16 output, no residual / activation / second output, alpha = 1 -> one 16-byte store
+        const int b = fdiv(m, p.fd_ohw), pix = m - b * p.OHW, no = (n0 >> 1) + jo, ncols = p.N >> 1;
+        bf16* o = reinterpret_cast<bf16*>(p.out) + (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld + no;
+        bf16x8 t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (bf16)v[q];
+        if (no + 7 < ncols && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0)) *reinterpret_cast<bf16x8*>(o) = t;
+        else
+          for (int q = 0; q < 8; ++q) if (no + q < ncols) o[q] = t[q];
+      } else {
+        epi8(p, m, (n0 >> 1) + jo, p.N >> 1, v);
+      }
     }
     return;
   }
@@ -722,8 +736,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, bool LEAN = false>
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev p) {
+  constexpr bool LEAN = EPI == 1;
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef ALDM_DIAG
   unsigned long long dg_t_entry; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_entry) :: "memory");
@@ -1025,7 +1040,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
       else mma_step(std::false_type{}, smem, LBs, ks, false);
     }
   }
-  igemm_epilogue<BM, BN, MI, NI, VT, NT, LEAN>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
+  igemm_epilogue<BM, BN, MI, NI, VT, NT, EPI>(p, acc, smem, vt_wg, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, lnst);
 #ifdef ALDM_DIAG
   if (p.diag && lane == 0) {
     unsigned long long dg_t_end; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_end) :: "memory");
@@ -1087,7 +1102,7 @@ static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev
   }
 }
 
-template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, bool LEAN = false>
+template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, int EPI = 0>
 int launch_cfg(const IgemmDev& d, hipStream_t st) {
   // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
   constexpr size_t lds_loop = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
@@ -1095,7 +1110,7 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   static bool attr_done = false;   // one-time, idempotent; races are benign
   void (*kern)(const IgemmDev);
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
-  else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S, LEAN>;
+  else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S, EPI>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { aldm_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -1117,9 +1132,9 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
   if (vt) {
     if constexpr (S != 0) {
       if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE) {   // LEAN V^T: no split / GEGLU / act code
-        if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S, true>(d, st);
-        if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S, true>(d, st);
-        return launch_cfg<BM, BN, WM, WN, 64, true, S, true>(d, st);
+        if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S, 1>(d, st);
+        if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, true, S, 1>(d, st);
+        return launch_cfg<BM, BN, WM, WN, 64, true, S, 1>(d, st);
       }
     }
     if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, true, S>(d, st);
@@ -1127,11 +1142,14 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
     return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
   }
   if constexpr (S != 0) {
+    if (Rp == 0 && d.geglu && d.splits <= 1 && !d.res && !d.res2 && !d.out2 && !d.out_f32 && d.out_act == ALDM_ACT_NONE &&
+        d.post_act == ALDM_ACT_NONE && d.alpha == 1.f)
+      return launch_cfg<BM, BN, WM, WN, 0, false, S, 2>(d, st);          // GEGLU-only epilogue with a plain bf16 store
     // the common case -- standard epilogue, no activation -- runs the LEAN instantiation (nothing else compiled in)
     if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE && !d.ln_s) {
-      if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S, true>(d, st);
-      if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S, true>(d, st);
-      return launch_cfg<BM, BN, WM, WN, 64, false, S, true>(d, st);
+      if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S, 1>(d, st);
+      if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S, 1>(d, st);
+      return launch_cfg<BM, BN, WM, WN, 64, false, S, 1>(d, st);
     }
   }
   if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S>(d, st);

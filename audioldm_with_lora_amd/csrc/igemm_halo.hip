@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   // rows of this tile past the bottom of the image alias the next image's first rows: cut M for the epilogue's bound checks
   IgemmDev q = p;
   q.M = min(p.M, min(m0 + BM, (img + 1) * p.OHW));
-  igemm_epilogue<BM, BN, MI, NI, false, NT, LEAN>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
+  igemm_epilogue<BM, BN, MI, NI, false, NT, LEAN ? 1 : 0>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
 #endif
 }
 
