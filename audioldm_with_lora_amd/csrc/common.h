@@ -34,7 +34,20 @@ static inline int aldm_launch_status(const char* what) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. exact for fp32-accumulated bf16 activations): 18 VALU instructions
+// against 38 for ocml's erff -- the GEGLU epilogue evaluates it 8.2 M times per feed-forward GEMM at the widest level.
+__device__ __forceinline__ float erf_as_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+  return copysignf(fmaf(-p, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {

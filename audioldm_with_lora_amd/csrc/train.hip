@@ -248,7 +248,7 @@ __global__ void geglu_bwd_kernel(const bf16* __restrict__ h, const bf16* __restr
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float gv = (float)g[k], dv = (float)d[k];
-    const float cdf = 0.5f * (1.f + erff(gv * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.f + erf_as_f(gv * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * gv * gv);
     da[k] = (bf16)(dv * gv * cdf);
     dg[k] = (bf16)(dv * (float)a[k] * (cdf + gv * pdf));
