@@ -91,7 +91,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
         float dz = (float)d[i][k];
         if (act == ALDM_ACT_SILU) {
           const float z = xh * gamma[c + k] + beta[c + k];
-          const float sg = 1.f / (1.f + __expf(-z));
+          const float sg = sigmoid_f(z);
           dz *= sg * (1.f + z * (1.f - sg));
         }
         const float gd = dz * gamma[c + k];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
         float dz = (float)d[i][k];
         if (act == ALDM_ACT_SILU) {
           const float z = xh * gamma[c + k] + beta[c + k];
-          const float sg = 1.f / (1.f + __expf(-z));
+          const float sg = sigmoid_f(z);
           dz *= sg * (1.f + z * (1.f - sg));
         }
         o[k] = (bf16)(rstd * (dz * gamma[c + k] - s1 - xh * s2));
