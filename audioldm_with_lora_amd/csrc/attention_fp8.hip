@@ -256,8 +256,8 @@ int launch8(const void* q, int ldq, const void* k, int ldk, const void* vt, int 
 template <int DP>
 int launch8_d(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N, int H, int D,
               float scale, void* out, int out_ld, hipStream_t st) {
-  if (N >= 512) return launch8<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
-  if (N >= 128) return launch8<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
+  if (N >= 192) return launch8<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
+  if (N >= 64) return launch8<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
   return launch8<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, st);
 }
 
