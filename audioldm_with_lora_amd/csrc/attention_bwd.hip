@@ -329,8 +329,8 @@ template <int DP>
 int launch_bwd_d(const void* q, const void* k, const void* v, int ld, const void* qT, const void* kT, const void* dOT, int ldt,
                  long long qt_bs, long long kt_bs, long long dot_bs, const void* dO, const void* O, int ldo, const float* lse,
                  float* delta, int B, int N, int H, int D, float scale, void* dq, void* dk, void* dv, int ldg, hipStream_t st) {
-  if (N >= 512) return launch_bwd<DP, 4>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
-  if (N >= 128) return launch_bwd<DP, 2>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
+  if (N >= 192) return launch_bwd<DP, 4>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
+  if (N >= 64) return launch_bwd<DP, 2>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
   return launch_bwd<DP, 1>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
 }
 
