@@ -263,6 +263,8 @@ int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt
                   int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   // measured in a replayed graph: N = 1000 (d 32) 4 waves 24 us vs 2 waves 31; N = 252 (d 48) 4 waves 8.9 us vs 2 waves 9.4;
   // N = 64 (d 80) 2 waves 5.6 us vs 1 wave 6.9 -- sharing one K / V^T staging among the waves beats more, smaller workgroups
+  // 8 waves (256 queries per workgroup) once that still leaves a workgroup per CU: 24.1 -> 22.9 us at N = 1000, 8 x 8 heads
+  if (N >= 768 && (long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
   if (N >= 192) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
   if (N >= 64) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
   return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
