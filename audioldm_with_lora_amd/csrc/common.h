@@ -33,6 +33,20 @@ static inline int aldm_launch_status(const char* what) {
   return ALDM_OK;
 }
 
+// n / d for a launch-constant d (round-up magic number, exact for 0 <= n < 2^31): a hardware integer division is ~40 instructions
+struct AldmDiv { unsigned mul, shift; };
+__device__ __forceinline__ int aldm_div(int n, AldmDiv d) {
+  return (int)(((unsigned long long)__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
+}
+static inline AldmDiv aldm_make_div(unsigned d) {
+  AldmDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+  return f;
+}
+
 // sigmoid / SiLU through v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE fp32 division costs ~10 more VALU instructions per element
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }

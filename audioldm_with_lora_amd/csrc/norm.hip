@@ -29,7 +29,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __res
                                                                int HW, int C1, int C2, int groups, float eps,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int act,
-                                                               bf16* __restrict__ y) {
+                                                               bf16* __restrict__ y, AldmDiv dqpp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x4* cache = reinterpret_cast<bf16x4*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)GN_LDS_QUADS * 8);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __res
   const int tid = threadIdx.x;
 
   auto load_quad = [&](int q) -> bf16x4 {
-    const int pix = q / qpp, j = q - pix * qpp;
+    const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
     const int c = c0 + 4 * j;
     if (c < C1) return *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c);
     return *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __res
 
   for (int q = tid; q < nquads; q += GN_THREADS) {
     const bf16x4 v = cached ? cache[q] : load_quad(q);
-    const int pix = q / qpp, j = q - pix * qpp;
+    const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
     const int c = c0 + 4 * j;
     bf16x4 o;
 #pragma unroll
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
                                                                    int HW, int C1, int C2, int groups, float eps,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
-                                                                   bf16* __restrict__ y) {
+                                                                   bf16* __restrict__ y, AldmDiv dqpp) {
   __shared__ float red[GN_THREADS / 64];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
     const int q = tid + i * GN_THREADS;
     bf16x4 t = {0, 0, 0, 0};
     if (q < nquads) {
-      const int pix = q / qpp, j = q - pix * qpp;
+      const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
       t = (c < C1) ? *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c)
                    : *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * GN_THREADS;
     if (q < nquads) {
-      const int pix = q / qpp, j = q - pix * qpp;
+      const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
       const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
@@ -293,16 +293,17 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
     attr_done = true;
   }
   const long long nquads = (long long)HW * (C / groups / 4);
+  const AldmDiv dq = aldm_make_div((unsigned)(C / groups / 4));
 #define ALDM_GN_REG(QPT)                                                                                               \
   hipLaunchKernelGGL(groupnorm_reg_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
-                     (const bf16*)x, (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y)
+                     (const bf16*)x, (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y, dq)
   if (nquads <= 4 * GN_THREADS) ALDM_GN_REG(4);
   else if (nquads <= 8 * GN_THREADS) ALDM_GN_REG(8);
   else if (nquads <= 16 * GN_THREADS) ALDM_GN_REG(16);
   else if (nquads <= 32 * GN_THREADS) ALDM_GN_REG(32);
   else
     hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16*)x,
-                       (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y);
+                       (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y, dq);
 #undef ALDM_GN_REG
   return aldm_launch_status("groupnorm");
 }

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
                                                                    int groups, float eps, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
                                                                    bf16* __restrict__ dx, bf16* __restrict__ dx2,
-                                                                   const bf16* dx_acc, const bf16* dx2_acc) {
+                                                                   const bf16* dx_acc, const bf16* dx2_acc, AldmDiv dqpp) {
   __shared__ float red[16];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
     const int q = tid + i * GN_THREADS;
     bf16x4 t = {0, 0, 0, 0}, u = {0, 0, 0, 0};
     if (q < nquads) {
-      const int pix = q / qpp, j = q - pix * qpp;
+      const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
       t = (c < C1) ? *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c)
                    : *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * GN_THREADS;
     if (q < nquads) {
-      const int j = q - (q / qpp) * qpp;
+      const int j = q - aldm_div(q, dqpp) * qpp;
       const int c = c0 + 4 * j;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * GN_THREADS;
     if (q < nquads) {
-      const int pix = q / qpp, j = q - pix * qpp;
+      const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
       bf16x4 o;
 #pragma unroll
@@ -541,11 +541,12 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
   const int C = C1 + C2;
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0 && (C2 == 0 || x2), "groupnorm_bwd: bad channels");
   const long long nquads = (long long)HW * (C / groups / 4);
+  const AldmDiv dq = aldm_make_div((unsigned)(C / groups / 4));
   ALDM_CHECK_ARG(nquads <= 32 * GN_THREADS, "groupnorm_bwd: strip of %lld quads exceeds the register-resident limit", nquads);
 #define ALDM_GNB(QPT)                                                                                                  \
   hipLaunchKernelGGL(groupnorm_bwd_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
                      (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
-                     (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc)
+                     (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc, dq)
   if (nquads <= 4 * GN_THREADS) ALDM_GNB(4);
   else if (nquads <= 8 * GN_THREADS) ALDM_GNB(8);
   else if (nquads <= 16 * GN_THREADS) ALDM_GNB(16);
