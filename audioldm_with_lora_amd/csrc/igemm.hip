@@ -43,6 +43,10 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
+  ALDM_CHECK_ARG(!(p->geglu && p->out2) || (p->Rp == 0 && p->splits <= 1 && !p->res && !p->res2 && p->out_dtype == ALDM_OUT_BF16 &&
+                                            p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE && p->alpha == 1.f &&
+                                            p->in_act == ALDM_ACT_NONE && p->Cin % 64 == 0 && p->Cin2 % 64 == 0 && p->Cout % 32 == 0),
+                 "igemm: GEGLU with out2 (pre-activation copy) needs the plain LDS-DMA GEGLU launch (no residual / activation / split-K)");
   ALDM_CHECK_ARG(!p->ln_s || (p->KH == 1 && p->KW == 1 && p->Cin2 == 0 && p->splits <= 1 && (p->Rp == 0 || (p->ln_sa && p->ln_ca))),
                  "igemm: folded LayerNorm needs a 1x1 single-source GEMM without split-K (and ln_sa/ln_ca with LoRA)");
   ALDM_CHECK_ARG(p->ring == 0 || (p->ring >= 2 && p->ring <= 4), "igemm: ring must be 0 (auto) or 2..4");

@@ -460,7 +460,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         v[q] = val * gelu_erf_f(gate);
       }
       if constexpr (GLEAN) {
-        // host-checked: bf16 output, no residual / activation / second output, alpha = 1 -> one 16-byte store
+        if (p.out2) {   // training: also keep the pre-activation projection h [M][N] (packed value | gate columns) for the backward
+          bf16* hrow = p.out2 + (long long)m * p.N + nv;
+          bf16x8 hv, hg;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float val = src[q], gate = src[16 + q];
+            if (lnst) {
+              val = lnst[BM + r] * (val - lnst[r] * p.ln_s[nv + q]);
+              gate = lnst[BM + r] * (gate - lnst[r] * p.ln_s[nv + 16 + q]);
+            }
+            if (p.bias) { val += p.bias[nv + q]; gate += p.bias[nv + 16 + q]; }
+            hv[q] = (bf16)val;
+            hg[q] = (bf16)gate;
+          }
+          *reinterpret_cast<bf16x8*>(hrow) = hv;
+          *reinterpret_cast<bf16x8*>(hrow + 16) = hg;
+        }
+        // host-checked: bf16 output, no residual / activation, alpha = 1 -> one 16-byte store
         const int b = fdiv(m, p.fd_ohw), pix = m - b * p.OHW, no = (n0 >> 1) + jo, ncols = p.N >> 1;
         bf16* o = reinterpret_cast<bf16*>(p.out) + (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld + no;
         bf16x8 t;
@@ -1142,7 +1159,7 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
     return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
   }
   if constexpr (S != 0) {
-    if (Rp == 0 && d.geglu && d.splits <= 1 && !d.res && !d.res2 && !d.out2 && !d.out_f32 && d.out_act == ALDM_ACT_NONE &&
+    if (Rp == 0 && d.geglu && d.splits <= 1 && !d.res && !d.res2 && !d.out_f32 && d.out_act == ALDM_ACT_NONE &&
         d.post_act == ALDM_ACT_NONE && d.alpha == 1.f)
       return launch_cfg<BM, BN, WM, WN, 0, false, S, 2>(d, st);          // GEGLU-only epilogue with a plain bf16 store
     // the common case -- standard epilogue, no activation -- runs the LEAN instantiation (nothing else compiled in)

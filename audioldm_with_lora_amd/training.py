@@ -350,14 +350,28 @@ class LoraTrainer:
         h = self._attention(tape, tb.attn1, Pt.attn1, t_layernorm(tape, h, *Pt.ln[0]), h, B, N)
         h = self._attention(tape, tb.attn2, Pt.attn2, t_layernorm(tape, h, *Pt.ln[1]), h, B, N)
         n3 = t_layernorm(tape, h, *Pt.ln[2])
-        if "ff1_plain" not in Pt.__dict__:                    # un-fused GEGLU, LayerNorm NOT folded (the backward needs LN(h))
+        if "ff1_plain" not in Pt.__dict__:                    # LayerNorm NOT folded (the backward needs LN(h))
             gp = ops.pack_geglu(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
-            Pt.ff1_plain = ops.PackedW(gp.w, gp.bias, gp.N, gp.Cin)
+            Pt.ff1_plain = ops.PackedW(gp.w, gp.bias, gp.N, gp.Cin)           # same packed rows, plain-linear view (for dX)
+            Pt.ff1_geglu = gp
         ff1 = Pt.ff1_plain
-        hp = t_view(tape, t_conv(tape, t_view(tape, n3, (1, 1, B * N, C)), ff1), (B * N, 8 * C))
-        g = Var(ops.geglu_fwd(hp.t), hp.rg)
-        if hp.rg:
-            tape.record(lambda: acc(hp, ops.geglu_bwd(hp.t, g.g)) if g.g is not None else None)
+        if C % 64 == 0:
+            # one GEGLU GEMM writes g = value * gelu(gate) AND keeps the pre-activation projection for the backward
+            M = B * N
+            hp_t = torch.empty(M, 8 * C, dtype=torch.bfloat16, device=n3.t.device)
+            g = Var(ops.conv(n3.t.view(1, 1, M, C), Pt.ff1_geglu, out2=hp_t, splits=1).view(M, 4 * C), n3.rg)
+            if n3.rg:
+                def bwd_ff1():
+                    if g.g is None:
+                        return
+                    dhp = ops.geglu_bwd(hp_t, g.g)
+                    put(n3, ops.conv(dhp.view(1, 1, M, 8 * C), _bwd_pack(ff1, 0, C), res=prior(n3, n3.t.view(1, 1, M, C))).view(M, C))
+                tape.record(bwd_ff1)
+        else:                                                 # narrow test configurations: un-fused projection + GEGLU kernels
+            hp = t_view(tape, t_conv(tape, t_view(tape, n3, (1, 1, B * N, C)), ff1), (B * N, 8 * C))
+            g = Var(ops.geglu_fwd(hp.t), hp.rg)
+            if hp.rg:
+                tape.record(lambda: acc(hp, ops.geglu_bwd(hp.t, g.g)) if g.g is not None else None)
         h4 = t_view(tape, h, (1, 1, B * N, C))
         h = t_conv(tape, t_view(tape, g, (1, 1, B * N, 4 * C)), Pt.ff2, res=h4)
         return t_conv(tape, t_view(tape, h, (B, H, W, C)), Pt.proj_out, res=x)

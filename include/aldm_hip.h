@@ -80,7 +80,9 @@ typedef struct {
   int out_act;  float out_slope;
   const void* res;  const void* res2;   /* bf16, addressed exactly like out */
   float alpha;
-  int post_act;  float post_slope;  void* out2;     /* out2: bf16, addressed exactly like out */
+  int post_act;  float post_slope;  void* out2;     /* out2: bf16, addressed exactly like out.  With geglu = 1: out2 receives the
+                                                       PRE-activation projection [M][Cout] (packed value | gate columns, bias added)
+                                                       that the GEGLU backward needs -- plain GEGLU launches only */
   void* out;  int out_dtype;  int out_ld;           /* columns per output row */
   long long out_batch_stride;                       /* elements between batches */
   int out_pix_stride, out_pix_offset;               /* row = pix*stride + offset (conv_transpose phases) */
