@@ -230,7 +230,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
                                                int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid,
                                                const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
-  constexpr bool LEAN = EPI == 1, GLEAN = EPI == 2;
+  constexpr bool LEAN = EPI == 1, GLEAN = EPI == 2, SLEAN = EPI == 3;   // 3: split-K launches -- only the partial-tile store
   float* Cs = reinterpret_cast<float*>(smem);
   if constexpr (LEAN && !VT) lnst = nullptr;               // LEAN keeps the V^T tile and the LayerNorm fold only in VT kernels
 
@@ -243,7 +243,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
   static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
   const int r0 = tid / GPR, c = (tid % GPR) * 8, n = n0 + c;
-  const bool std_path = !GLEAN && !(VT && vt_wg) && (LEAN || (p.splits <= 1 && !p.geglu));
+  const bool std_path = !GLEAN && !SLEAN && !(VT && vt_wg) && (LEAN || (p.splits <= 1 && !p.geglu));
   const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
   const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
   float colb[8], lns[8];
@@ -424,7 +424,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     return;
   }
   if constexpr (!LEAN) {
-  if (!GLEAN && p.splits > 1) {
+  if (!GLEAN && (SLEAN || p.splits > 1)) {
     for (int g = tid; g < BM * (BN / 8); g += NT) {
       const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
       const int m = m0 + r, n = n0 + c;
@@ -440,7 +440,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     }
     return;
   }
-  if (GLEAN || p.geglu) {
+  if (!SLEAN && (GLEAN || p.geglu)) {
     // image columns come in blocks of (16 value | 16 gate); 8 output columns = 8 values and their 8 gates
     for (int g = tid; g < BM * (BN / 16); g += NT) {
       const int r = g / (BN / 16), jo = (g - r * (BN / 16)) * 8;        // jo: output column inside the tile
@@ -1159,6 +1159,11 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
     return launch_cfg<BM, BN, WM, WN, 64, true, S>(d, st);
   }
   if constexpr (S != 0) {
+    if (d.splits > 1) {                                                   // split-K: only the partial-tile store is compiled in
+      if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S, 3>(d, st);
+      if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S, 3>(d, st);
+      return launch_cfg<BM, BN, WM, WN, 64, false, S, 3>(d, st);
+    }
     if (Rp == 0 && d.geglu && d.splits <= 1 && !d.res && !d.res2 && !d.out_f32 && d.out_act == ALDM_ACT_NONE &&
         d.post_act == ALDM_ACT_NONE && d.alpha == 1.f)
       return launch_cfg<BM, BN, WM, WN, 0, false, S, 2>(d, st);          // GEGLU-only epilogue with a plain bf16 store
