@@ -99,6 +99,7 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aldm_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
     "aldm_sleep_us": (C.c_int, [C.c_int, C.c_void_p]),
+    "aldm_gather_row": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "aldm_advance_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_log_mel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

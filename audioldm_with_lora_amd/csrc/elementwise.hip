@@ -89,6 +89,17 @@ __global__ void advance_step_kernel(int* step_idx, const float* __restrict__ tim
   }
 }
 
+// out[0 .. row_elems) = table[idx[0]][0 .. row_elems): selects the current DDIM step's row of a precomputed per-step table (the
+// time-embedding projections of all steps are computed once per prompt, see engine.py) with a DEVICE-side index, so the replayed
+// graph needs no host work between steps.
+__global__ __launch_bounds__(256) void gather_row_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                                         long long row_elems, float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= row_elems) return;
+  const float* src = table + (long long)idx[0] * row_elems + i;
+  *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(src);
+}
+
 __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
                                   float bc1, float bc2_sqrt, float gscale) {
@@ -178,6 +189,12 @@ extern "C" int aldm_advance_step(int* step_idx, const float* timesteps, int n_st
   ALDM_CHECK_ARG(step_idx && timesteps && t_out && n_steps > 0, "advance_step: bad args");
   hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_idx, timesteps, n_steps, t_out);
   return aldm_launch_status("advance_step");
+}
+
+extern "C" int aldm_gather_row(const float* table, const int* idx, long long row_elems, float* out, void* stream) {
+  ALDM_CHECK_ARG(table && idx && out && row_elems > 0 && row_elems % 4 == 0, "gather_row: bad args (row_elems %% 4 == 0)");
+  hipLaunchKernelGGL(gather_row_kernel, dim3(blocks_for(row_elems / 4, 256)), dim3(256), 0, (hipStream_t)stream, table, idx, row_elems, out);
+  return aldm_launch_status("gather_row");
 }
 
 extern "C" int aldm_adamw_flat(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,

@@ -43,6 +43,8 @@ class DenoiseEngine:
         self.t_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
         self.cls = None
+        self.temb = None             # [chains][n_steps, nbc, temb_total] fp32: time-embedding projections of every step
+        self.rowbias = None          # [chains][nbc, temb_total] fp32: the current step's row (gathered on the device)
         self.graph = None
         self._side = None
 
@@ -62,6 +64,14 @@ class DenoiseEngine:
         else:
             for dst, src in zip(self.cls, new):
                 dst.copy_(src)
+        # everything the UNet derives from (timestep, prompt) alone is computed here once for the whole schedule
+        tabs = [self.unet.temb_table(self.timesteps_f32, c) for c in self.cls]
+        if self.temb is None:
+            self.temb = tabs
+            self.rowbias = [torch.empty_like(t[0]) for t in tabs]
+        else:
+            for dst, src in zip(self.temb, tabs):
+                dst.copy_(src)
 
     def set_latents(self, latents_nchw):
         """latents [B, C, H, W] fp32 (already multiplied by init_noise_sigma = 1)."""
@@ -77,7 +87,8 @@ class DenoiseEngine:
         self.t_buf.copy_(self.timesteps_f32[:1])
 
     def _chain_step(self, i):
-        eps = self.unet.forward_nhwc(self.x_in[i], self.t_buf, self.cls[i])
+        ops.gather_row(self.temb[i], self.step_idx, self.rowbias[i])
+        eps = self.unet.forward_nhwc(self.x_in[i], self.t_buf, self.cls[i], rowbias=self.rowbias[i])
         ops.cfg_ddim_step(eps, self.x[i * self.bc:(i + 1) * self.bc], self.cfg, self.g, self.coef, self.step_idx, self.x_in[i])
 
     def _one_step(self):

@@ -588,6 +588,13 @@ def sleep_us(us):
     check(_lib.load().aldm_sleep_us(int(us), _stream()), "aldm_sleep_us")
 
 
+def gather_row(table, idx, out):
+    """out[...] = table[idx[0]] (device-side index); table [n, ...] fp32 contiguous, out one row."""
+    row = table[0].numel()
+    assert table.dtype == torch.float32 and out.dtype == torch.float32 and out.numel() == row and idx.dtype == torch.int32
+    check(_lib.load().aldm_gather_row(_p(table), _p(idx), row, _p(out), _stream()), "aldm_gather_row")
+
+
 def advance_step(step_idx, timesteps_f32, t_out):
     check(_lib.load().aldm_advance_step(_p(step_idx), _p(timesteps_f32), timesteps_f32.numel(), _p(t_out), _stream()),
           "aldm_advance_step")

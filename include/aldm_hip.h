@@ -188,6 +188,10 @@ int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n_per_sample
 int aldm_sleep_us(int us, void* stream);
 /* device-side loop counter for graph replay: step_idx[0] = (step_idx[0] + 1) mod n_steps ; t_out[0] = timesteps[step_idx[0]] */
 int aldm_advance_step(int* step_idx, const float* timesteps, int n_steps, float* t_out, void* stream);
+/* out[0..row_elems) = table[idx[0]][0..row_elems) with a device-side row index: the engine precomputes the time-embedding
+   projections (`time_emb_proj` of all 22 resnets) of EVERY DDIM step once per prompt and each replayed step selects its row --
+   the five-launch embedding chain of UNet2DConditionModel.forward leaves the per-step graph. */
+int aldm_gather_row(const float* table, const int* idx, long long row_elems, float* out, void* stream);
 
 /* noisy[b][i] = coef[b][0]*x[b][i] + coef[b][1]*noise[b][i]  (DDIMScheduler.add_noise,
    [REF script/train/train_audioldm_lora.py:504]); fp32 in, fp32 out; coef fp32 [B][2] = {sqrt(abar_t), sqrt(1-abar_t)} */
