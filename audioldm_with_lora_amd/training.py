@@ -372,6 +372,9 @@ class LoraTrainer:
             g = Var(ops.geglu_fwd(hp.t), hp.rg)
             if hp.rg:
                 tape.record(lambda: acc(hp, ops.geglu_bwd(hp.t, g.g)) if g.g is not None else None)
+        if Pt.ff2_proj is not None:           # ff2 and proj_out as one GEMM over the virtual concat [g | h] (see unet._merge_ff2_proj_out);
+            # its dX splits back into dg = dy (Wp W2) and dh = dy Wp -- the same two backward GEMMs as before
+            return t_conv(tape, t_view(tape, g, (B, H, W, 4 * C)), Pt.ff2_proj, x2=t_view(tape, h, (B, H, W, C)), res=x)
         h4 = t_view(tape, h, (1, 1, B * N, C))
         h = t_conv(tape, t_view(tape, g, (1, 1, B * N, 4 * C)), Pt.ff2, res=h4)
         return t_conv(tape, t_view(tape, h, (B, H, W, C)), Pt.proj_out, res=x)
