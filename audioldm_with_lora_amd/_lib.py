@@ -44,6 +44,7 @@ class IgemmArgs(C.Structure):
         ("splits", C.c_int), ("workspace", C.c_void_p),
         ("tile", C.c_int),
         ("ring", C.c_int),
+        ("defer_reduce", C.c_int),
     ]
 
 
@@ -53,6 +54,9 @@ PROTOTYPES = {
     "aldm_last_error": (C.c_char_p, []),
     "aldm_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
     "aldm_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmArgs)]),
+    "aldm_igemm_effective_splits": (C.c_int, [C.POINTER(IgemmArgs)]),
+    "aldm_groupnorm_partials": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,

@@ -27,6 +27,14 @@ extern "C" size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p) {
   return (size_t)p->splits * M * p->Cout * sizeof(float);
 }
 
+extern "C" int aldm_igemm_effective_splits(const aldm_igemm_t* p) {
+  if (!p || p->splits <= 1) return 1;
+  const int nkt = cdiv(p->KH * p->KW * (p->Cin + p->Cin2), BK);
+  int splits = p->splits > nkt ? nkt : p->splits;
+  const int per = cdiv(nkt, splits);
+  return cdiv(nkt, per);
+}
+
 extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(p && p->x && p->w && p->out, "igemm: null x/w/out");
   ALDM_CHECK_ARG(p->B > 0 && p->IH > 0 && p->IW > 0 && p->OH > 0 && p->OW > 0 && p->Cout > 0, "igemm: bad dims");
@@ -43,6 +51,8 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
+  ALDM_CHECK_ARG(!p->defer_reduce || (!p->geglu && !p->res && !p->res2 && !p->out2 && p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE && p->alpha == 1.f),
+                 "igemm: defer_reduce leaves bias / row bias to the consumer and supports nothing else in the epilogue");
   ALDM_CHECK_ARG(!(p->geglu && p->out2) || (p->Rp == 0 && p->splits <= 1 && !p->res && !p->res2 && p->out_dtype == ALDM_OUT_BF16 &&
                                             p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE && p->alpha == 1.f &&
                                             p->in_act == ALDM_ACT_NONE && p->Cin % 64 == 0 && p->Cin2 % 64 == 0 && p->Cout % 32 == 0),
@@ -110,7 +120,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;
   }
   if (rc != ALDM_OK) return rc;
-  if (d.splits > 1) {
+  if (d.splits > 1 && !p->defer_reduce) {
     const int ncols = d.geglu ? d.N / 2 : d.N;
     const long long work = (long long)d.M * (ncols / 4);
     hipLaunchKernelGGL(igemm_reduce_kernel, dim3((unsigned)cdivll(work, 256)), dim3(256), 0, st, d);

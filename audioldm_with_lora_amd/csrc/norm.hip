@@ -150,6 +150,99 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
   }
 }
 
+// GroupNorm(+SiLU) over split-K partial tiles (aldm_groupnorm_partials): the strip is summed out of the fp32 workspace
+// [splits][B*HW][C] in split order (as igemm_reduce_kernel sums), bias and the per-image row bias (the time-embedding
+// projection of ResnetBlock2D) are added, and the fp32 strip stays in registers for the statistics.
+template <int QPT>
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const float* __restrict__ ws, int splits, long long sstride,
+                                                                        int HW, int C, int groups, float eps,
+                                                                        const float* __restrict__ bias,
+                                                                        const float* __restrict__ rowbias, int rowbias_ld,
+                                                                        const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, int act,
+                                                                        bf16* __restrict__ y, AldmDiv dqpp) {
+  __shared__ float red[GN_THREADS / 64];
+  const int Cg = C / groups, qpp = Cg >> 2;
+  const int nb = gridDim.x / groups;
+  const int g = blockIdx.x / nb, b = blockIdx.x - g * nb;
+  const int c0 = g * Cg;
+  const int nquads = HW * qpp;
+  const int tid = threadIdx.x;
+
+  f32x4 v[QPT];
+  long long off[QPT];
+  int ch[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + i * GN_THREADS;
+    const int qq = q < nquads ? q : 0;
+    const int pix = aldm_div(qq, dqpp), j = qq - pix * qpp;
+    ch[i] = c0 + 4 * j;
+    off[i] = ((long long)b * HW + pix) * C + ch[i];
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int sp = 0;
+  for (; sp + 4 <= splits; sp += 4) {
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+      if (tid + i * GN_THREADS < nquads) {
+        const float* w0 = ws + off[i] + sp * sstride;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(w0), a1 = *reinterpret_cast<const f32x4*>(w0 + sstride);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(w0 + 2 * sstride), a3 = *reinterpret_cast<const f32x4*>(w0 + 3 * sstride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] = (((v[i][k] + a0[k]) + a1[k]) + a2[k]) + a3[k];
+      }
+    }
+  }
+  for (; sp < splits; ++sp) {
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+      if (tid + i * GN_THREADS < nquads) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ws + off[i] + sp * sstride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] += a[k];
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (tid + i * GN_THREADS < nquads) {
+      const int c = ch[i];
+      if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + c); v[i] += t; }
+      if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + (long long)b * rowbias_ld + c); v[i] += t; }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float n = (float)nquads * 4.f;
+  const float mean = block_sum(s, red, tid, GN_THREADS) / n;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (tid + i * GN_THREADS < nquads) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(block_sum(ss, red, tid, GN_THREADS) / n + eps);
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (tid + i * GN_THREADS < nquads) {
+      const int c = ch[i];
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+      bf16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = (v[i][k] - mean) * (gm[k] * rstd) + bt[k];
+        if (act == ALDM_ACT_SILU) t = silu_f(t);
+        o[k] = (bf16)t;
+      }
+      *reinterpret_cast<bf16x4*>(y + off[i]) = o;
+    }
+  }
+}
+
 // LayerNorm: LPR lanes per row (a full wave, or half a wave when the row has <= 32 16-byte chunks, i.e. C <= 256 -- the
 // widest level of the UNet -- so that no lane idles), 16-byte chunks, C <= LPR*8*MAXC.
 constexpr int LN_MAXC = 4;  // chunks per lane -> C <= 2048
@@ -306,6 +399,28 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
                        (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y, dq);
 #undef ALDM_GN_REG
   return aldm_launch_status("groupnorm");
+}
+
+extern "C" int aldm_groupnorm_partials(const float* ws, int splits, int B, int HW, int C, const float* bias,
+                                       const float* rowbias, int rowbias_ld, int groups, float eps, const float* gamma,
+                                       const float* beta, int act, void* y, void* stream) {
+  ALDM_CHECK_ARG(ws && y && gamma && beta && splits >= 1, "groupnorm_partials: null pointer / bad splits");
+  ALDM_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
+                 "groupnorm_partials: group width must be a multiple of 4");
+  ALDM_CHECK_ARG(!rowbias || rowbias_ld >= C, "groupnorm_partials: rowbias_ld");
+  const long long nquads = (long long)HW * (C / groups / 4);
+  ALDM_CHECK_ARG(nquads <= 8 * GN_THREADS, "groupnorm_partials: strip of %lld quads exceeds the register-resident limit %d", nquads, 8 * GN_THREADS);
+  const AldmDiv dq = aldm_make_div((unsigned)(C / groups / 4));
+  const long long sstride = (long long)B * HW * C;
+#define ALDM_GNP(QPT)                                                                                                  \
+  hipLaunchKernelGGL(groupnorm_partials_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream, ws,   \
+                     splits, sstride, HW, C, groups, eps, bias, rowbias, rowbias_ld, gamma, beta, act, (bf16*)y, dq)
+  if (nquads <= GN_THREADS) ALDM_GNP(1);
+  else if (nquads <= 2 * GN_THREADS) ALDM_GNP(2);
+  else if (nquads <= 4 * GN_THREADS) ALDM_GNP(4);
+  else ALDM_GNP(8);
+#undef ALDM_GNP
+  return aldm_launch_status("groupnorm_partials");
 }
 
 extern "C" int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,

@@ -262,6 +262,7 @@ class Tuner:
         for t, rg, sp in cands:
             a.tile, a.ring, a.splits = t, rg, sp
             a.workspace = ws.data_ptr() if sp > 1 else None
+            a.defer_reduce = 1 if (sp > 1 and key.endswith(" gn")) else 0   # the consumer GroupNorm pays the reduce
             if lib.aldm_igemm(C.byref(a), _stream()) != 0:              # warm-up doubles as the validity check
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -345,8 +346,12 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0, ring=0):
-    """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2])."""
+         splits=None, tile=0, ring=0, gn=None):
+    """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
+
+    gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
+    is split-K the partial tiles are summed by the GroupNorm kernel itself (aldm_groupnorm_partials) and the convolution's
+    bf16 output is never written (ResnetBlock2D.conv1 -> norm2 -> SiLU)."""
     _require_gpu(x)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
     B, IH, IW, C1 = x.shape
@@ -410,13 +415,17 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     M = B * OH * OW
     ktiles = pw.Kpad // BK
     can_split = not (vt is not None or pw.N % 4 or pw.ln_s is not None)
+    gn_defer = (gn is not None and can_split and not pw.geglu and res is None and res2 is None and out2 is None
+                and out_act == ACT_NONE and post_act == ACT_NONE and alpha == 1.0 and out.dtype == torch.bfloat16
+                and out_ld == pw.N and out_pix_stride == 1 and pw.N % gn[2] == 0 and (pw.N // gn[2]) % 4 == 0
+                and OH * OW * (pw.N // gn[2] // 4) <= 4096)
     fast_path = not (pw.Cin % 64 or (x2 is not None and x2.shape[3] % 64) or in_act)
     tuning = False
     if tile == 0 and ring == 0:
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
-                       pw.ln_s is not None, fast_path) + ("" if splits is None else f" sp{splits}")
+                       pw.ln_s is not None, fast_path) + ("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "")
         cfg = TUNED.get(key)
         tuning = TUNER is not None and not torch.cuda.is_current_stream_capturing()
         if tuning:
@@ -438,22 +447,40 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         a.workspace = _workspace(splits * M * pw.N * 4, x.device).data_ptr()
     a.tile = tile
     a.ring = ring
+    lib = _lib.load()
+    eff = lib.aldm_igemm_effective_splits(C.byref(a)) if (gn_defer and splits > 1) else 1
+    a.defer_reduce = 1 if eff > 1 else 0
     ktot = KH * KW * pw.Cin
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)
     nbytes = 2.0 * (B * IH * IW * pw.Cin + pw.N * ktot + M * ncols)
     label = (f"igemm_{TILE_NAMES[tile]}_r{pw.Rp}{'_vt' if vt is not None else ''}{'_sk' if splits > 1 else ''}"
              f"|M{M} N{pw.N} K{ktot}{' geglu' if pw.geglu else ''}")
-    lib = _lib.load()
+
+    def finish():
+        # the GroupNorm of gn=: over the partial tiles when the launch deferred its reduce, else over the bf16 output
+        if gn is None:
+            return out
+        gamma, beta, groups, eps, act = gn
+        if eff <= 1:
+            return groupnorm(out, gamma, beta, groups, eps, act)
+        y = torch.empty(B, OH, OW, pw.N, dtype=torch.bfloat16, device=x.device)
+        n = M * pw.N
+        check(_launch(f"groupnorm_partials|HW{OH * OW} C{pw.N} S{eff}", 10.0 * n, (4.0 * eff + 2.0) * n, lambda: lib.aldm_groupnorm_partials(
+            a.workspace, eff, B, OH * OW, pw.N, a.bias, a.rowbias, a.rowbias_ld, groups, eps, _p(gamma), _p(beta), act, _p(y),
+            _stream())), "aldm_groupnorm_partials")
+        return y
+
     if tuning and TUNER.slot is not None:                      # stage 2 of the tuner: time this launch in context
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = lib.aldm_igemm(C.byref(a), _stream())
-        e1.record()
         check(rc, "aldm_igemm")
+        y = finish() if gn_defer else None                     # a deferred reduce is paid by the GroupNorm: time both
+        e1.record()
         TUNER.record(key, (tile, ring, splits), e0, e1)
-        return out
+        return y if gn_defer else finish()
     check(_launch(label, flops, nbytes, lambda: lib.aldm_igemm(C.byref(a), _stream())), "aldm_igemm")
-    return out
+    return finish()
 
 
 def linear(x2d: torch.Tensor, pw: PackedW, **kw):

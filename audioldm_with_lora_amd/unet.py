@@ -229,8 +229,8 @@ def pack_transformer(t: Transformer2DModel):
 def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0):
     h = ops.groupnorm(x, P.g1, P.b1, P.groups, P.eps, ACT_SILU, x2=x2)
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
-    h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld)
-    h = ops.groupnorm(h, P.g2, P.b2, P.groups, P.eps, ACT_SILU)
+    # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
+    h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=(P.g2, P.b2, P.groups, P.eps, ACT_SILU))
     if P.shortcut is not None:
         xs = ops.conv(x, P.shortcut, x2=x2)
     else:

@@ -92,6 +92,8 @@ typedef struct {
   int splits;  float* workspace;                    /* [splits][M][Cout] fp32 when splits > 1 */
   int tile;                 /* 0 = auto, else ALDM_TILE_* */
   int ring;                 /* 0 = auto, else LDS-DMA ring depth 2..4 (tuning) */
+  int defer_reduce;         /* split-K only: leave the partial tiles in `workspace` and launch no reduce -- the consumer sums
+                               them itself (aldm_groupnorm_partials, for conv1 -> GroupNorm2 of a ResnetBlock2D) */
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
@@ -102,6 +104,8 @@ enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE
 
 int aldm_igemm(const aldm_igemm_t* p, void* stream);
 size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p);
+/* the split count the launch will really use (splits is clamped so that every split gets whole 64-wide K-tiles) */
+int aldm_igemm_effective_splits(const aldm_igemm_t* p);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over channels-last x [B][HW][C1] (optionally the virtual channel
@@ -115,6 +119,12 @@ int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2,
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
 int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,
                    void* stream);
+/* GroupNorm (+SiLU) whose input is still split-K partial tiles: x[m][c] = sum_s ws[s][m][c] + bias[c] + rowbias[b][c]
+   (ws fp32 [splits][B*HW][C], as left by aldm_igemm with defer_reduce).  Fuses the split-K reduce of ResnetBlock2D.conv1
+   (bias + time-embedding projection) with norm2 + SiLU: one launch and no bf16 round trip of the conv output. */
+int aldm_groupnorm_partials(const float* ws, int splits, int B, int HW, int C, const float* bias, const float* rowbias,
+                            int rowbias_ld, int groups, float eps, const float* gamma, const float* beta, int act, void* y,
+                            void* stream);
 /* ClapTextEmbeddings: y[b*L+j] = LayerNorm(word[ids[b][j]] + type0 + pos[pid]) as bf16 [B*L][C]; pid counts the non-pad
    tokens up to and including j (offset by pad_idx; pad tokens use pid = pad_idx).  ids int64 on the device, fp32 tables.
    First op of `text_encoder(input_ids, attention_mask)` [REF script/train/train_audioldm_lora.py:513-518]. */

@@ -124,6 +124,33 @@ def test_conv_splitk_matches(ops):
         close(to_nchw(y), want)
 
 
+@pytest.mark.parametrize("B,C,Cout,H,W,groups,splits", [
+    (8, 128, 640, 16, 4, 32, 4),      # one quad slot per thread, UNet L3 shape
+    (2, 64, 384, 63, 4, 32, 3),       # two slots, ragged strip (L2 shape)
+    (1, 64, 128, 40, 16, 8, 5),       # eight slots; 5 splits exercise the tail of the split loop
+    (2, 64, 96, 9, 4, 8, 1),          # not split: the ordinary conv -> GroupNorm pair behind the same call
+])
+def test_conv_groupnorm_over_split_partials(ops, B, C, Cout, H, W, groups, splits):
+    """conv(gn=...) == GroupNorm(SiLU) of the convolution (bias + row bias), the reduce of a split-K launch fused into the norm."""
+    g = torch.Generator().manual_seed(17)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = bf(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout + 40, generator=g)
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    conv = F.conv2d(x, w, b, padding=1) + temb[:, 40:, None, None]
+    want = F.silu(F.group_norm(conv, groups, gamma, beta, 1e-5))
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    td = temb.to(DEV)
+    y = ops.conv(nhwc(x), pw, pad=(1, 1), rowbias=td[:, 40:], rowbias_ld=Cout + 40, splits=splits,
+                 gn=(gamma.to(DEV), beta.to(DEV), groups, 1e-5, ops.ACT_SILU))
+    close(to_nchw(y), want, rtol=1.5e-2)
+    # and the unfused pair agrees with it to bf16 rounding of the intermediate
+    h = ops.conv(nhwc(x), pw, pad=(1, 1), rowbias=td[:, 40:], rowbias_ld=Cout + 40, splits=splits)
+    y2 = ops.groupnorm(h, gamma.to(DEV), beta.to(DEV), groups, 1e-5, ops.ACT_SILU)
+    close(y.float().cpu(), y2.float().cpu(), rtol=2e-2)
+
+
 def test_conv_two_sources_rowbias_residual_f32out(ops):
     g = torch.Generator().manual_seed(2)
     x1 = bf(torch.randn(2, 96, 10, 8, generator=g))
