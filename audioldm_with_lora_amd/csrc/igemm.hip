@@ -51,8 +51,8 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(!p->vt || p->vt_col0 > 0 || p->out, "igemm: out required");
   ALDM_CHECK_ARG(p->splits <= 1 || (p->workspace && p->Cout % 4 == 0), "igemm: split-K needs workspace and Cout %% 4 == 0");
   ALDM_CHECK_ARG(p->out_ld > 0, "igemm: out_ld");
-  ALDM_CHECK_ARG(!p->defer_reduce || (!p->geglu && !p->res && !p->res2 && !p->out2 && p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE && p->alpha == 1.f),
-                 "igemm: defer_reduce leaves bias / row bias to the consumer and supports nothing else in the epilogue");
+  ALDM_CHECK_ARG(!p->defer_reduce || (!p->geglu && !p->res2 && !p->out2 && p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE && p->alpha == 1.f),
+                 "igemm: defer_reduce leaves bias / row bias / res to the consumer and supports nothing else in the epilogue");
   ALDM_CHECK_ARG(!(p->geglu && p->out2) || (p->Rp == 0 && p->splits <= 1 && !p->res && !p->res2 && p->out_dtype == ALDM_OUT_BF16 &&
                                             p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE && p->alpha == 1.f &&
                                             p->in_act == ALDM_ACT_NONE && p->Cin % 64 == 0 && p->Cin2 % 64 == 0 && p->Cout % 32 == 0),

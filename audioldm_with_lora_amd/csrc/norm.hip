@@ -158,6 +158,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
                                                                         int HW, int C, int groups, float eps,
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ rowbias, int rowbias_ld,
+                                                                        const bf16* __restrict__ res, bf16* __restrict__ sum_out,
                                                                         const float* __restrict__ gamma,
                                                                         const float* __restrict__ beta, int act,
                                                                         bf16* __restrict__ y, AldmDiv dqpp) {
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   const int tid = threadIdx.x;
 
   f32x4 v[QPT];
+  bf16x4 rv[QPT];
   long long off[QPT];
   int ch[QPT];
 #pragma unroll
@@ -180,6 +182,8 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
     ch[i] = c0 + 4 * j;
     off[i] = ((long long)b * HW + pix) * C + ch[i];
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rv[i] = bf16x4{0, 0, 0, 0};
+    if (res && q < nquads) rv[i] = *reinterpret_cast<const bf16x4*>(res + off[i]);   // in flight with the partial tiles
   }
   int sp = 0;
   for (; sp + 4 <= splits; sp += 4) {
@@ -211,6 +215,16 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
       const int c = ch[i];
       if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + c); v[i] += t; }
       if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + (long long)b * rowbias_ld + c); v[i] += t; }
+      if (res) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] += (float)rv[i][k];
+      }
+      if (sum_out) {
+        bf16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (bf16)v[i][k];
+        *reinterpret_cast<bf16x4*>(sum_out + off[i]) = o;
+      }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
   }
@@ -402,8 +416,8 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
 }
 
 extern "C" int aldm_groupnorm_partials(const float* ws, int splits, int B, int HW, int C, const float* bias,
-                                       const float* rowbias, int rowbias_ld, int groups, float eps, const float* gamma,
-                                       const float* beta, int act, void* y, void* stream) {
+                                       const float* rowbias, int rowbias_ld, const void* res, void* sum_out, int groups,
+                                       float eps, const float* gamma, const float* beta, int act, void* y, void* stream) {
   ALDM_CHECK_ARG(ws && y && gamma && beta && splits >= 1, "groupnorm_partials: null pointer / bad splits");
   ALDM_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
                  "groupnorm_partials: group width must be a multiple of 4");
@@ -414,7 +428,8 @@ extern "C" int aldm_groupnorm_partials(const float* ws, int splits, int B, int H
   const long long sstride = (long long)B * HW * C;
 #define ALDM_GNP(QPT)                                                                                                  \
   hipLaunchKernelGGL(groupnorm_partials_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream, ws,   \
-                     splits, sstride, HW, C, groups, eps, bias, rowbias, rowbias_ld, gamma, beta, act, (bf16*)y, dq)
+                     splits, sstride, HW, C, groups, eps, bias, rowbias, rowbias_ld, (const bf16*)res, (bf16*)sum_out, gamma, beta,    \
+                     act, (bf16*)y, dq)
   if (nquads <= GN_THREADS) ALDM_GNP(1);
   else if (nquads <= 2 * GN_THREADS) ALDM_GNP(2);
   else if (nquads <= 4 * GN_THREADS) ALDM_GNP(4);

@@ -346,12 +346,14 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0, ring=0, gn=None):
+         splits=None, tile=0, ring=0, gn=None, gn_keep=False):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
     is split-K the partial tiles are summed by the GroupNorm kernel itself (aldm_groupnorm_partials) and the convolution's
-    bf16 output is never written (ResnetBlock2D.conv1 -> norm2 -> SiLU)."""
+    bf16 output is never written (ResnetBlock2D.conv1 -> norm2 -> SiLU).  gn_keep=True returns (convolution, its GroupNorm)
+    -- ResnetBlock2D.conv2 (+ shortcut `res`) in front of a Transformer2DModel's norm: the block output stays on the residual
+    stream and the fused kernel writes both."""
     _require_gpu(x)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
     B, IH, IW, C1 = x.shape
@@ -415,7 +417,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     M = B * OH * OW
     ktiles = pw.Kpad // BK
     can_split = not (vt is not None or pw.N % 4 or pw.ln_s is not None)
-    gn_defer = (gn is not None and can_split and not pw.geglu and res is None and res2 is None and out2 is None
+    gn_defer = (gn is not None and can_split and not pw.geglu and res2 is None and out2 is None
                 and out_act == ACT_NONE and post_act == ACT_NONE and alpha == 1.0 and out.dtype == torch.bfloat16
                 and out_ld == pw.N and out_pix_stride == 1 and pw.N % gn[2] == 0 and (pw.N // gn[2]) % 4 == 0
                 and OH * OW * (pw.N // gn[2] // 4) <= 4096)
@@ -462,13 +464,14 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             return out
         gamma, beta, groups, eps, act = gn
         if eff <= 1:
-            return groupnorm(out, gamma, beta, groups, eps, act)
+            y = groupnorm(out, gamma, beta, groups, eps, act)
+            return (out, y) if gn_keep else y
         y = torch.empty(B, OH, OW, pw.N, dtype=torch.bfloat16, device=x.device)
         n = M * pw.N
         check(_launch(f"groupnorm_partials|HW{OH * OW} C{pw.N} S{eff}", 10.0 * n, (4.0 * eff + 2.0) * n, lambda: lib.aldm_groupnorm_partials(
-            a.workspace, eff, B, OH * OW, pw.N, a.bias, a.rowbias, a.rowbias_ld, groups, eps, _p(gamma), _p(beta), act, _p(y),
-            _stream())), "aldm_groupnorm_partials")
-        return y
+            a.workspace, eff, B, OH * OW, pw.N, a.bias, a.rowbias, a.rowbias_ld, a.res, (a.out if gn_keep else None), groups, eps,
+            _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm_partials")
+        return (out, y) if gn_keep else y
 
     if tuning and TUNER.slot is not None:                      # stage 2 of the tuner: time this launch in context
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

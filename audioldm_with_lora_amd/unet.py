@@ -226,7 +226,9 @@ def pack_transformer(t: Transformer2DModel):
 # ----------------------------------------------------------------------------------------------
 # launch sequences
 # ----------------------------------------------------------------------------------------------
-def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0):
+def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None):
+    """ResnetBlock2D over x (| x2).  next_gn = (gamma, beta, groups, eps, act) of a GroupNorm that consumes the block output
+    (the Transformer2DModel behind it): returns (output, its GroupNorm), the norm fused with conv2's split-K reduce."""
     h = ops.groupnorm(x, P.g1, P.b1, P.groups, P.eps, ACT_SILU, x2=x2)
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
     # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
@@ -236,6 +238,8 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0):
     else:
         assert x2 is None
         xs = x
+    if next_gn is not None:
+        return ops.conv(h, P.conv2, pad=(1, 1), res=xs, gn=next_gn, gn_keep=True)
     return ops.conv(h, P.conv2, pad=(1, 1), res=xs)
 
 
@@ -249,10 +253,15 @@ def run_attention(P, hn, h_res, B, N, fp8=False):
     return ops.linear(a, P.out, res=h_res)
 
 
-def run_transformer(P, x, fp8=False):
+def transformer_gn(P):
+    return (P.gn_g, P.gn_b, P.groups, 1e-6, ACT_NONE)
+
+
+def run_transformer(P, x, fp8=False, xn=None):
+    """Transformer2DModel over x; xn = its GroupNorm when the producer already computed it (run_resnet next_gn)."""
     B, H, W, C = x.shape
     N = H * W
-    h = ops.groupnorm(x, P.gn_g, P.gn_b, P.groups, 1e-6, ACT_NONE)
+    h = xn if xn is not None else ops.groupnorm(x, *transformer_gn(P))
     h = ops.conv(h, P.proj_in).view(B * N, C)
     # LayerNorms are folded into the consuming GEMM where possible (row statistics computed in-kernel)
     h = run_attention(P.attn1, h if P.attn1.ln_folded else ops.layernorm(h, *P.ln[0]), h, B, N, fp8)
@@ -424,21 +433,25 @@ class UNet2DConditionModel(nn.Module):
         skips = [h]
         for blk in P.down:
             for i, r in enumerate(blk.resnets):
-                h = run_resnet(r, h, None, rowbias, ld)
                 if blk.attns is not None:
-                    h = run_transformer(blk.attns[i], h, fp8)
+                    h, hn = run_resnet(r, h, None, rowbias, ld, next_gn=transformer_gn(blk.attns[i]))
+                    h = run_transformer(blk.attns[i], h, fp8, xn=hn)
+                else:
+                    h = run_resnet(r, h, None, rowbias, ld)
                 skips.append(h)
             if blk.down is not None:
                 h = ops.conv(h, blk.down, stride=(2, 2), pad=(1, 1))
                 skips.append(h)
-        h = run_resnet(P.mid.resnets[0], h, None, rowbias, ld)
-        h = run_transformer(P.mid.attns[0], h, fp8)
+        h, hn = run_resnet(P.mid.resnets[0], h, None, rowbias, ld, next_gn=transformer_gn(P.mid.attns[0]))
+        h = run_transformer(P.mid.attns[0], h, fp8, xn=hn)
         h = run_resnet(P.mid.resnets[1], h, None, rowbias, ld)
         for bi, blk in enumerate(P.up):
             for i, r in enumerate(blk.resnets):
-                h = run_resnet(r, h, skips.pop(), rowbias, ld)
                 if blk.attns is not None:
-                    h = run_transformer(blk.attns[i], h, fp8)
+                    h, hn = run_resnet(r, h, skips.pop(), rowbias, ld, next_gn=transformer_gn(blk.attns[i]))
+                    h = run_transformer(blk.attns[i], h, fp8, xn=hn)
+                else:
+                    h = run_resnet(r, h, skips.pop(), rowbias, ld)
             if blk.up is not None:
                 if forward_upsample_size:
                     size = (skips[-1].shape[1], skips[-1].shape[2])

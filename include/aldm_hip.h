@@ -93,7 +93,8 @@ typedef struct {
   int tile;                 /* 0 = auto, else ALDM_TILE_* */
   int ring;                 /* 0 = auto, else LDS-DMA ring depth 2..4 (tuning) */
   int defer_reduce;         /* split-K only: leave the partial tiles in `workspace` and launch no reduce -- the consumer sums
-                               them itself (aldm_groupnorm_partials, for conv1 -> GroupNorm2 of a ResnetBlock2D) */
+                               them itself and adds bias / rowbias / res (aldm_groupnorm_partials: ResnetBlock2D convs
+                               in front of a GroupNorm) */
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
@@ -119,12 +120,15 @@ int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2,
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
 int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,
                    void* stream);
-/* GroupNorm (+SiLU) whose input is still split-K partial tiles: x[m][c] = sum_s ws[s][m][c] + bias[c] + rowbias[b][c]
-   (ws fp32 [splits][B*HW][C], as left by aldm_igemm with defer_reduce).  Fuses the split-K reduce of ResnetBlock2D.conv1
-   (bias + time-embedding projection) with norm2 + SiLU: one launch and no bf16 round trip of the conv output. */
+/* GroupNorm (+SiLU) whose input is still split-K partial tiles:
+     x[m][c] = sum_s ws[s][m][c] + bias[c] + rowbias[b][c] + res[m][c]
+   (ws fp32 [splits][B*HW][C], as left by aldm_igemm with defer_reduce; bias / rowbias / res may be NULL).  Fuses the split-K
+   reduce of ResnetBlock2D.conv1 (bias + time-embedding projection) with norm2 + SiLU, and that of conv2 (bias + shortcut
+   residual `res`, bf16 [B*HW][C]) with the norm of the Transformer2DModel that follows: one launch instead of two.
+   sum_out (bf16 [B*HW][C], may be NULL) receives x itself -- the block output the residual stream carries on. */
 int aldm_groupnorm_partials(const float* ws, int splits, int B, int HW, int C, const float* bias, const float* rowbias,
-                            int rowbias_ld, int groups, float eps, const float* gamma, const float* beta, int act, void* y,
-                            void* stream);
+                            int rowbias_ld, const void* res, void* sum_out, int groups, float eps, const float* gamma,
+                            const float* beta, int act, void* y, void* stream);
 /* ClapTextEmbeddings: y[b*L+j] = LayerNorm(word[ids[b][j]] + type0 + pos[pid]) as bf16 [B*L][C]; pid counts the non-pad
    tokens up to and including j (offset by pad_idx; pad tokens use pid = pad_idx).  ids int64 on the device, fp32 tables.
    First op of `text_encoder(input_ids, attention_mask)` [REF script/train/train_audioldm_lora.py:513-518]. */

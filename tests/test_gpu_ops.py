@@ -149,6 +149,14 @@ def test_conv_groupnorm_over_split_partials(ops, B, C, Cout, H, W, groups, split
     h = ops.conv(nhwc(x), pw, pad=(1, 1), rowbias=td[:, 40:], rowbias_ld=Cout + 40, splits=splits)
     y2 = ops.groupnorm(h, gamma.to(DEV), beta.to(DEV), groups, 1e-5, ops.ACT_SILU)
     close(y.float().cpu(), y2.float().cpu(), rtol=2e-2)
+    # conv2 form: shortcut residual joins the sum, the block output is kept next to its (activation-free) norm
+    r = bf(torch.randn(B, Cout, H, W, generator=g))
+    want_h = F.conv2d(x, w, b, padding=1) + r
+    want_n = F.group_norm(want_h, groups, gamma, beta, 1e-6)
+    hk, yn = ops.conv(nhwc(x), pw, pad=(1, 1), res=nhwc(r), splits=splits, gn=(gamma.to(DEV), beta.to(DEV), groups, 1e-6, ops.ACT_NONE),
+                      gn_keep=True)
+    close(to_nchw(hk), want_h)
+    close(to_nchw(yn), want_n, rtol=1.5e-2)
 
 
 def test_conv_two_sources_rowbias_residual_f32out(ops):
