@@ -26,7 +26,7 @@ import torch
 from . import dp, ops
 from ._lib import ACT_NONE, ACT_SILU
 from .lora import LoraLinear
-from .unet import UNet2DConditionModel
+from .unet import UNet2DConditionModel, transformer_gn
 
 BK = 64
 
@@ -99,10 +99,14 @@ def t_view(tape, x, shape):
     return y
 
 
-def t_conv(tape, x, pw, x2=None, stride=(1, 1), pad=(0, 0), up_size=None, rowbias=None, rowbias_ld=0, res=None, out_f32=False):
+def t_conv(tape, x, pw, x2=None, stride=(1, 1), pad=(0, 0), up_size=None, rowbias=None, rowbias_ld=0, res=None, out_f32=False, _gn=None):
     """Frozen conv / linear (no LoRA): forward = ops.conv, backward = dX only."""
-    y = Var(ops.conv(x.t, pw, x2=(x2.t if x2 is not None else None), stride=stride, pad=pad, up_size=up_size,
-                     rowbias=rowbias, rowbias_ld=rowbias_ld, res=(res.t if res is not None else None), out_f32=out_f32, splits=1 if out_f32 else None))
+    out = ops.conv(x.t, pw, x2=(x2.t if x2 is not None else None), stride=stride, pad=pad, up_size=up_size,
+                   rowbias=rowbias, rowbias_ld=rowbias_ld, res=(res.t if res is not None else None), out_f32=out_f32, splits=1 if out_f32 else None,
+                   gn=(_gn[0] if _gn else None), gn_keep=bool(_gn))
+    if _gn:
+        out, _gn[1]["y"] = out                     # t_conv_gn: the GroupNorm of the output came out of the same launches
+    y = Var(out)
     y.rg = x.rg or (x2 is not None and x2.rg) or (res is not None and res.rg)
     if not y.rg:
         return y
@@ -129,8 +133,16 @@ def t_conv(tape, x, pw, x2=None, stride=(1, 1), pad=(0, 0), up_size=None, rowbia
     return y
 
 
-def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None):
-    y = Var(ops.groupnorm(x.t, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None)))
+def t_conv_gn(tape, x, pw, gn, **kw):
+    """t_conv then t_groupnorm(*gn) with the two forwards fused (ops.conv gn=: a split-K conv's reduce rides in the norm);
+    returns (conv output, its GroupNorm) -- the backward is the unfused pair's."""
+    box = {}
+    y = t_conv(tape, x, pw, _gn=(gn, box), **kw)
+    return y, t_groupnorm(tape, y, *gn, fwd=box["y"])
+
+
+def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None, fwd=None):
+    y = Var(fwd if fwd is not None else ops.groupnorm(x.t, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None)))
     y.rg = x.rg or (x2 is not None and x2.rg)
     if y.rg:
         def bwd():
@@ -341,11 +353,11 @@ class LoraTrainer:
         y = t_conv(tape, t_view(tape, o, (1, 1, B * N, C)), Pa.out, res=t_view(tape, h_res, (1, 1, B * N, C)))
         return t_view(tape, y, (B * N, C))
 
-    def _transformer(self, tape, tmod, Pt, x):
+    def _transformer(self, tape, tmod, Pt, x, xn=None):
         B, H, W, C = x.shape
         N = H * W
         tb = tmod.transformer_blocks[0]
-        h = t_groupnorm(tape, x, Pt.gn_g, Pt.gn_b, Pt.groups, 1e-6, ACT_NONE)
+        h = xn if xn is not None else t_groupnorm(tape, x, *transformer_gn(Pt))
         h = t_view(tape, t_conv(tape, h, Pt.proj_in), (B * N, C))
         h = self._attention(tape, tb.attn1, Pt.attn1, t_layernorm(tape, h, *Pt.ln[0]), h, B, N)
         h = self._attention(tape, tb.attn2, Pt.attn2, t_layernorm(tape, h, *Pt.ln[1]), h, B, N)
@@ -380,11 +392,14 @@ class LoraTrainer:
         return t_conv(tape, t_view(tape, h, (B, H, W, C)), Pt.proj_out, res=x)
 
     @staticmethod
-    def _resnet(tape, Pr, x, x2, rowbias, ld):
+    def _resnet(tape, Pr, x, x2, rowbias, ld, next_gn=None):
+        """next_gn: GroupNorm of the Transformer2DModel behind the block -> returns (output, its norm) as unet.run_resnet"""
         h = t_groupnorm(tape, x, Pr.g1, Pr.b1, Pr.groups, Pr.eps, ACT_SILU, x2=x2)
-        h = t_conv(tape, h, Pr.conv1, pad=(1, 1), rowbias=rowbias[:, Pr.temb_off:], rowbias_ld=ld)
-        h = t_groupnorm(tape, h, Pr.g2, Pr.b2, Pr.groups, Pr.eps, ACT_SILU)
+        _, h = t_conv_gn(tape, h, Pr.conv1, (Pr.g2, Pr.b2, Pr.groups, Pr.eps, ACT_SILU), pad=(1, 1),
+                         rowbias=rowbias[:, Pr.temb_off:], rowbias_ld=ld)
         xs = t_conv(tape, x, Pr.shortcut, x2=x2) if Pr.shortcut is not None else x
+        if next_gn is not None:
+            return t_conv_gn(tape, h, Pr.conv2, next_gn, pad=(1, 1), res=xs)
         return t_conv(tape, h, Pr.conv2, pad=(1, 1), res=xs)
 
     def forward(self, tape, x_in, t_dev, cls_bf16):
@@ -408,21 +423,25 @@ class LoraTrainer:
         skips = [h]
         for blk, Pb in zip(u.down_blocks, P.down):
             for i, r in enumerate(Pb.resnets):
-                h = self._resnet(tape, r, h, None, rowbias, ld)
                 if Pb.attns is not None:
-                    h = self._transformer(tape, blk.attentions[i], Pb.attns[i], h)
+                    h, hn = self._resnet(tape, r, h, None, rowbias, ld, next_gn=transformer_gn(Pb.attns[i]))
+                    h = self._transformer(tape, blk.attentions[i], Pb.attns[i], h, xn=hn)
+                else:
+                    h = self._resnet(tape, r, h, None, rowbias, ld)
                 skips.append(h)
             if Pb.down is not None:
                 h = t_conv(tape, h, Pb.down, stride=(2, 2), pad=(1, 1))
                 skips.append(h)
-        h = self._resnet(tape, P.mid.resnets[0], h, None, rowbias, ld)
-        h = self._transformer(tape, u.mid_block.attentions[0], P.mid.attns[0], h)
+        h, hn = self._resnet(tape, P.mid.resnets[0], h, None, rowbias, ld, next_gn=transformer_gn(P.mid.attns[0]))
+        h = self._transformer(tape, u.mid_block.attentions[0], P.mid.attns[0], h, xn=hn)
         h = self._resnet(tape, P.mid.resnets[1], h, None, rowbias, ld)
         for blk, Pb in zip(u.up_blocks, P.up):
             for i, r in enumerate(Pb.resnets):
-                h = self._resnet(tape, r, h, skips.pop(), rowbias, ld)
                 if Pb.attns is not None:
-                    h = self._transformer(tape, blk.attentions[i], Pb.attns[i], h)
+                    h, hn = self._resnet(tape, r, h, skips.pop(), rowbias, ld, next_gn=transformer_gn(Pb.attns[i]))
+                    h = self._transformer(tape, blk.attentions[i], Pb.attns[i], h, xn=hn)
+                else:
+                    h = self._resnet(tape, r, h, skips.pop(), rowbias, ld)
             if Pb.up is not None:
                 size = (skips[-1].shape[1], skips[-1].shape[2]) if fus else (h.shape[1] * 2, h.shape[2] * 2)
                 h = t_conv(tape, h, Pb.up, pad=(1, 1), up_size=size)
