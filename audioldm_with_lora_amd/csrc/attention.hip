@@ -9,6 +9,7 @@
 // UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546].  Head dims 32/48/80
 // (8 heads at C = 256/384/640), sequence lengths 1000/252/64 (10 s) and 1024/256/64 (training).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -22,10 +23,14 @@ struct AttnCfg {
   static constexpr int KS = DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);  // K LDS row stride (odd number of 16-B slots)
   static constexpr int KBYTES = KV * KS;
   static constexpr int VBYTES = DT * 32 * VS;
-  static constexpr int LDS = 2 * (KBYTES + VBYTES);
+  static constexpr int TILE = KBYTES + VBYTES;
 };
 
-template <int DP, int NW>
+// SP > 1 splits the KEYS of a query block over SP waves (wave groups): every iteration stages SP tiles of 64 keys, group g
+// works on tile g, and the groups' (max, sum, O^T) are merged through LDS at the end.  At N = 1000 / 252 with 8 x 8 heads a
+// query block per wave gives only 2 / 0.5 waves per SIMD; the split doubles the independent instruction streams that hide
+// the MFMA -> softmax -> MFMA dependency chain.
+template <int DP, int NW, int SP>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restrict__ q, int ldq,
                                                             const bf16* __restrict__ k, int ldk,
                                                             const bf16* __restrict__ vt, int vt_ld, long long vt_bs,
@@ -38,10 +43,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   constexpr int KCH = KV * (DP / 8);        // 16-B chunks in a K tile
   constexpr int VCH = DP * (KV / 8);        // 16-B chunks in a V^T tile
   constexpr int KPT = (KCH + T - 1) / T, VPT = (VCH + T - 1) / T;
+  constexpr int QW = NW / SP;               // query blocks (of 32) per workgroup
+  static_assert(NW % SP == 0, "waves must divide into key groups");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                              // [2][KV][KS]
-  char* Vs = smem + 2 * Cfg::KBYTES;            // [2][DT*32][VS]
+  char* Ks = smem;                              // [2][SP][KV][KS]
+  char* Vs = smem + 2 * SP * Cfg::KBYTES;       // [2][SP][DT*32][VS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -61,7 +68,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       head = pair - b * H;
     }
   }
-  const int q0 = (qblk * NW + wave) * 32;
+  const int grp = wave / QW;                    // key group of this wave
+  const int q0 = (qblk * QW + (wave - grp * QW)) * 32;
   const bf16* qb = q + (long long)b * N * ldq + head * D;
   const bf16* kb = k + (long long)b * N * ldk + head * D;
   const bf16* vb = vt + (long long)b * vt_bs + (long long)head * D * vt_ld;
@@ -69,10 +77,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // keys 0 .. Nk-1 of this batch item take part (right-padded text batches pass their true lengths; the key loop
   // then stops at the last valid tile instead of masking 512-token padding)
   const int Nk = kv_len ? max(1, min(kv_len[b], N)) : N;
-  if (kv_len && qblk * NW * 32 >= Nk) {
+  if (kv_len && qblk * QW * 32 >= Nk) {
     // every query of this workgroup is padding: its rows are never read as keys, so write zeros and leave
-    for (int i = tid; i < NW * 32 * (D / 4); i += T) {
-      const int row = qblk * NW * 32 + i / (D / 4), c4 = i % (D / 4);
+    for (int i = tid; i < QW * 32 * (D / 4); i += T) {
+      const int row = qblk * QW * 32 + i / (D / 4), c4 = i % (D / 4);
       if (row < N) *reinterpret_cast<uint2*>(out + ((long long)b * N + row) * out_ld + head * D + c4 * 4) = make_uint2(0u, 0u);
     }
     return;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // zero the d-padding rows of both V^T buffers once (rows D .. DT*32-1 stay zero for the whole kernel)
   {
     const int npad = DT * 32 - D;                      // rows to clear per buffer (0 when D is a multiple of 32)
-    for (int i = tid; i < 2 * npad * (VS / 8); i += T) {
+    for (int i = tid; i < 2 * SP * npad * (VS / 8); i += T) {
       const int buf = i / (npad * (VS / 8)), rem = i - buf * npad * (VS / 8);
       reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + D * VS)[rem] = make_uint2(0u, 0u);
     }
@@ -95,15 +103,21 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     qf[ks] = (q0 + r < N && col < D) ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + r) * ldq + col) : zero8;
   }
 
-  bf16x8 kreg[KPT], vreg[VPT];
-  auto prefetch = [&](int kv0) {
+  // two register sets: the loads of tile-group it+2 are issued at the top of iteration it and written to LDS at the bottom of
+  // iteration it+1 -- two iterations of flight time (one iteration, ~0.5 us, does not cover an L2 miss)
+  bf16x8 kreg[2][SP][KPT], vreg[2][SP][VPT];
+  auto prefetch = [&](int kvbase, auto setc) {
+   constexpr int SET = decltype(setc)::value;
+#pragma unroll
+   for (int j = 0; j < SP; ++j) {
+    const int kv0 = kvbase + j * KV;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int cidx = tid + i * T;
       const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
       bf16x8 v = zero8;
       if (cidx < KCH && kv0 + row < Nk && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(kb + (long long)(kv0 + row) * ldk + ch * 8);
-      kreg[i] = v;
+      kreg[SET][j][i] = v;
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -118,15 +132,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
           for (int j = 0; j < 8; ++j) if (kvb + j >= Nk) v[j] = (bf16)0.f;
         }
       }
-      vreg[i] = v;
+      vreg[SET][j][i] = v;
     }
+   }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, auto setc) {
+   constexpr int SET = decltype(setc)::value;
+#pragma unroll
+   for (int j = 0; j < SP; ++j) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int cidx = tid + i * T;
       const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
-      if (cidx < KCH) *reinterpret_cast<bf16x8*>(Ks + buf * Cfg::KBYTES + row * KS + ch * 16) = kreg[i];
+      if (cidx < KCH) *reinterpret_cast<bf16x8*>(Ks + (buf * SP + j) * Cfg::KBYTES + row * KS + ch * 16) = kreg[SET][j][i];
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -134,12 +152,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       const int row = cidx >> 3, ch = cidx & 7;
       if (cidx < VCH) {
         // rows are 136 B apart: 8-byte aligned only -> two 8-byte stores
-        uint2* dst = reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + row * VS + ch * 16);
-        const uint4 u = __builtin_bit_cast(uint4, vreg[i]);
+        uint2* dst = reinterpret_cast<uint2*>(Vs + (buf * SP + j) * Cfg::VBYTES + row * VS + ch * 16);
+        const uint4 u = __builtin_bit_cast(uint4, vreg[SET][j][i]);
         dst[0] = make_uint2(u.x, u.y);
         dst[1] = make_uint2(u.z, u.w);
       }
     }
+   }
   };
 
   f32x16 o[DT];
@@ -150,13 +169,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (Nk + KV - 1) / KV;
-  prefetch(0);
-  stage(0);
+  const int niter = (ntiles + SP - 1) / SP;
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  prefetch(0, Set0{});
+  if (niter > 1) prefetch(SP * KV, Set1{});
+  stage(0, Set0{});
   __syncthreads();
 
-  for (int it = 0; it < ntiles; ++it) {
-    const int buf = it & 1, kv0 = it * KV;
-    if (it + 1 < ntiles) prefetch(kv0 + KV);
+  auto iteration = [&](int it, auto curc) {     // curc: the register set that is free (its tile-group was staged last iteration)
+    constexpr int CUR = decltype(curc)::value;
+    const int buf = (it & 1) * SP + grp, kv0 = (it * SP + grp) * KV;
+    if (it + 2 < niter) prefetch((it + 2) * SP * KV, curc);
+    if (SP == 1 || kv0 < Nk) {                 // (wave-uniform) a group past the last tile of an odd count sits this one out
 
     // ---- S^T = K Q^T for two 32-key sub-tiles ----
     f32x16 s[2];
@@ -217,8 +242,44 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[t], 0, 0, 0);
       }
-    if (it + 1 < ntiles) stage(buf ^ 1);
+    }
+    if (it + 1 < niter) stage((it & 1) ^ 1, std::integral_constant<int, CUR ^ 1>{});
     __syncthreads();
+  };
+  for (int it = 0; it < niter; it += 2) {
+    iteration(it, Set0{});
+    if (it + 1 < niter) iteration(it + 1, Set1{});
+  }
+
+  if constexpr (SP > 1) {
+    // ---- merge the key groups: groups 1.. leave (m, l, O^T) in LDS (the staging buffers are dead after the last barrier),
+    // group 0 folds them in.  Layout [value][lane] per wave: conflict-free 4-byte accesses. ----
+    constexpr int WVALS = DT * 16 + 2;
+    float* xch = reinterpret_cast<float*>(smem);
+    if (grp > 0) {
+      float* mine = xch + ((grp - 1) * QW + (wave - grp * QW)) * WVALS * 64;
+      mine[lane] = m_run;
+      mine[64 + lane] = l_run;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[(2 + t * 16 + i) * 64 + lane] = o[t][i];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < SP; ++g) {
+      const float* peer = xch + ((g - 1) * QW + wave) * WVALS * 64;
+      const float m1 = peer[lane], l1 = peer[64 + lane];
+      const float m_new = fmaxf(m_run, m1);                      // m_run is finite: group 0 always owns tile 0
+      const float a0 = __builtin_amdgcn_exp2f(m_run - m_new), a1 = __builtin_amdgcn_exp2f(m1 - m_new);   // a1 = 0 for an idle group
+      m_run = m_new;
+      l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * a0 + peer[(2 + t * 16 + i) * 64 + lane] * a1;
+    }
   }
 
   // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
@@ -241,19 +302,21 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   }
 }
 
-template <int DP, int NW>
+template <int DP, int NW, int SP = 1>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
                 int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   using Cfg = AttnCfg<DP>;
-  auto kern = attention_kernel<DP, NW>;
+  auto kern = attention_kernel<DP, NW, SP>;
+  constexpr int LDS = 2 * SP * Cfg::TILE;
+  static_assert(SP == 1 || (SP - 1) * (NW / SP) * (Cfg::DT * 16 + 2) * 256 <= LDS, "merge buffer must fit the staging area");
   static bool attr_done = false;
-  if (!attr_done && Cfg::LDS > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  if (!attr_done && LDS > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) { aldm_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   attr_done = true;
-  dim3 grid(cdiv(N, 32 * NW), H, B);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), Cfg::LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt,
+  dim3 grid(cdiv(N, 32 * (NW / SP)), H, B);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt,
                      vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld, lse, kv_len);
   return aldm_launch_status("attention");
 }
@@ -264,8 +327,16 @@ int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt
   // measured in a replayed graph: N = 1000 (d 32) 4 waves 24 us vs 2 waves 31; N = 252 (d 48) 4 waves 8.9 us vs 2 waves 9.4;
   // N = 64 (d 80) 2 waves 5.6 us vs 1 wave 6.9 -- sharing one K / V^T staging among the waves beats more, smaller workgroups
   // 8 waves (256 queries per workgroup) once that still leaves a workgroup per CU: 24.1 -> 22.9 us at N = 1000, 8 x 8 heads
-  if (N >= 768 && (long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
-  if (N >= 192) return launch_attn<DP, 4>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
+  // keys split over two wave groups (SP = 2) where a query block per wave leaves SIMDs idle: N = 252 (d 48) 9.0 -> 7.2 us,
+  // N = 1000 with 4 heads 16.6 -> 14.6 us; at N = 1000 x 64 (batch, head) pairs the kernel is VALU-throughput-bound (softmax)
+  // and the split only adds the merge: 22.9 -> 23.4 us, so the full-size case keeps one wave per query block
+#define ALDM_ATTN_ARGS q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st
+  if (N >= 768) {
+    if ((long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8>(ALDM_ATTN_ARGS);
+    return launch_attn<DP, 8, 2>(ALDM_ATTN_ARGS);
+  }
+  if (N >= 192) return launch_attn<DP, 4, 2>(ALDM_ATTN_ARGS);
+#undef ALDM_ATTN_ARGS
   if (N >= 64) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
   return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
 }
