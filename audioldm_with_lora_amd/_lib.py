@@ -56,8 +56,8 @@ PROTOTYPES = {
     "aldm_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmArgs)]),
     "aldm_igemm_effective_splits": (C.c_int, [C.POINTER(IgemmArgs)]),
     "aldm_groupnorm_partials": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                          C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
-                                          C.c_void_p, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,

@@ -159,11 +159,15 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ rowbias, int rowbias_ld,
                                                                         const bf16* __restrict__ res, bf16* __restrict__ sum_out,
+                                                                        const bf16* __restrict__ x2, int C2,
                                                                         const float* __restrict__ gamma,
                                                                         const float* __restrict__ beta, int act,
                                                                         bf16* __restrict__ y, AldmDiv dqpp) {
+  // C = channels of the partial tiles (first source); C2 more channels come as plain bf16 from x2 (torch.cat([h, skip]) in
+  // front of an up-block ResnetBlock2D's norm1).  A group lies wholly in one source (host-checked: C % group width == 0).
   __shared__ float red[GN_THREADS / 64];
-  const int Cg = C / groups, qpp = Cg >> 2;
+  const int Ct = C + C2;
+  const int Cg = Ct / groups, qpp = Cg >> 2;
   const int nb = gridDim.x / groups;
   const int g = blockIdx.x / nb, b = blockIdx.x - g * nb;
   const int c0 = g * Cg;
@@ -172,8 +176,9 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
 
   f32x4 v[QPT];
   bf16x4 rv[QPT];
-  long long off[QPT];
+  long long off[QPT], yoff[QPT];
   int ch[QPT];
+  const bool second = c0 >= C;                 // (workgroup-uniform) this group's channels come from x2
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * GN_THREADS;
@@ -181,10 +186,16 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
     const int pix = aldm_div(qq, dqpp), j = qq - pix * qpp;
     ch[i] = c0 + 4 * j;
     off[i] = ((long long)b * HW + pix) * C + ch[i];
+    yoff[i] = ((long long)b * HW + pix) * Ct + ch[i];
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     rv[i] = bf16x4{0, 0, 0, 0};
-    if (res && q < nquads) rv[i] = *reinterpret_cast<const bf16x4*>(res + off[i]);   // in flight with the partial tiles
+    if (second) {
+      if (q < nquads) rv[i] = *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (ch[i] - C));
+    } else if (res && q < nquads) {
+      rv[i] = *reinterpret_cast<const bf16x4*>(res + off[i]);   // in flight with the partial tiles
+    }
   }
+  if (second) splits = 0;
   int sp = 0;
   for (; sp + 4 <= splits; sp += 4) {
 #pragma unroll
@@ -213,13 +224,15 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   for (int i = 0; i < QPT; ++i) {
     if (tid + i * GN_THREADS < nquads) {
       const int c = ch[i];
-      if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + c); v[i] += t; }
-      if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + (long long)b * rowbias_ld + c); v[i] += t; }
-      if (res) {
+      if (!second) {
+        if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + c); v[i] += t; }
+        if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + (long long)b * rowbias_ld + c); v[i] += t; }
+      }
+      if (second || res) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[i][k] += (float)rv[i][k];
       }
-      if (sum_out) {
+      if (sum_out && !second) {
         bf16x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (bf16)v[i][k];
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
         if (act == ALDM_ACT_SILU) t = silu_f(t);
         o[k] = (bf16)t;
       }
-      *reinterpret_cast<bf16x4*>(y + off[i]) = o;
+      *reinterpret_cast<bf16x4*>(y + yoff[i]) = o;
     }
   }
 }
@@ -416,20 +429,23 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
 }
 
 extern "C" int aldm_groupnorm_partials(const float* ws, int splits, int B, int HW, int C, const float* bias,
-                                       const float* rowbias, int rowbias_ld, const void* res, void* sum_out, int groups,
-                                       float eps, const float* gamma, const float* beta, int act, void* y, void* stream) {
+                                       const float* rowbias, int rowbias_ld, const void* res, void* sum_out,
+                                       const void* x2, int C2, int groups, float eps, const float* gamma, const float* beta,
+                                       int act, void* y, void* stream) {
   ALDM_CHECK_ARG(ws && y && gamma && beta && splits >= 1, "groupnorm_partials: null pointer / bad splits");
-  ALDM_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
-                 "groupnorm_partials: group width must be a multiple of 4");
+  ALDM_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C2 >= 0 && groups > 0 && (C2 == 0 || x2), "groupnorm_partials: bad dims");
+  const int Ct = C + C2;
+  ALDM_CHECK_ARG(Ct % groups == 0 && (Ct / groups) % 4 == 0 && C % (Ct / groups) == 0,
+                 "groupnorm_partials: group width %d must be a multiple of 4 and divide the first source's %d channels", Ct / groups, C);
   ALDM_CHECK_ARG(!rowbias || rowbias_ld >= C, "groupnorm_partials: rowbias_ld");
-  const long long nquads = (long long)HW * (C / groups / 4);
+  const long long nquads = (long long)HW * (Ct / groups / 4);
   ALDM_CHECK_ARG(nquads <= 8 * GN_THREADS, "groupnorm_partials: strip of %lld quads exceeds the register-resident limit %d", nquads, 8 * GN_THREADS);
-  const AldmDiv dq = aldm_make_div((unsigned)(C / groups / 4));
+  const AldmDiv dq = aldm_make_div((unsigned)(Ct / groups / 4));
   const long long sstride = (long long)B * HW * C;
 #define ALDM_GNP(QPT)                                                                                                  \
   hipLaunchKernelGGL(groupnorm_partials_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream, ws,   \
-                     splits, sstride, HW, C, groups, eps, bias, rowbias, rowbias_ld, (const bf16*)res, (bf16*)sum_out, gamma, beta,    \
-                     act, (bf16*)y, dq)
+                     splits, sstride, HW, C, groups, eps, bias, rowbias, rowbias_ld, (const bf16*)res, (bf16*)sum_out,        \
+                     (const bf16*)x2, C2, gamma, beta, act, (bf16*)y, dq)
   if (nquads <= GN_THREADS) ALDM_GNP(1);
   else if (nquads <= 2 * GN_THREADS) ALDM_GNP(2);
   else if (nquads <= 4 * GN_THREADS) ALDM_GNP(4);

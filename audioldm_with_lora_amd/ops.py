@@ -342,18 +342,46 @@ def _workspace(nbytes, device):
     return t
 
 
+class Deferred:
+    """A split-K convolution whose reduce is still pending (conv(..., defer=True)): the fp32 partial tiles sit in the shared
+    workspace, `out` is the bf16 tensor the consumer will fill.  The ONLY valid consumer is the next groupnorm() call on this
+    stream -- it sums the tiles, adds bias / row bias / residual, writes `out` and returns the norm; no other split-K conv may
+    run in between (the workspace is shared; conv() refuses)."""
+    __slots__ = ("out", "ws", "eff", "bias", "rowbias", "rowbias_ld", "res", "keep")
+
+    def __init__(self, out, ws, eff, bias, rowbias, rowbias_ld, res, keep):
+        self.out, self.ws, self.eff, self.bias, self.rowbias, self.rowbias_ld, self.res = out, ws, eff, bias, rowbias, rowbias_ld, res
+        self.keep = keep                                   # tensors the pointers above refer to
+
+    @property
+    def shape(self):
+        return self.out.shape
+
+
+_PENDING = None                                            # the Deferred whose partial tiles currently own the workspace
+
+
+def tensor_of(x):
+    """the bf16 tensor behind a conv result (for a Deferred: valid on the stream once its consumer norm has been launched)"""
+    return x.out if isinstance(x, Deferred) else x
+
+
 def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, stride=(1, 1), pad=(0, 0), dil=(1, 1),
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0, ring=0, gn=None, gn_keep=False):
+         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
     is split-K the partial tiles are summed by the GroupNorm kernel itself (aldm_groupnorm_partials) and the convolution's
     bf16 output is never written (ResnetBlock2D.conv1 -> norm2 -> SiLU).  gn_keep=True returns (convolution, its GroupNorm)
     -- ResnetBlock2D.conv2 (+ shortcut `res`) in front of a Transformer2DModel's norm: the block output stays on the residual
-    stream and the fused kernel writes both."""
+    stream and the fused kernel writes both.  defer=True: the same for a norm that is launched later by the caller -- returns
+    a Deferred (see there) when the launch is split-K, else the tensor as usual."""
+    global _PENDING
+    if _PENDING is not None:
+        raise _lib.AldmError("conv: a deferred split-K reduce is pending -- its consumer groupnorm() must be the next launch")
     _require_gpu(x)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
     B, IH, IW, C1 = x.shape
@@ -417,10 +445,15 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     M = B * OH * OW
     ktiles = pw.Kpad // BK
     can_split = not (vt is not None or pw.N % 4 or pw.ln_s is not None)
-    gn_defer = (gn is not None and can_split and not pw.geglu and res2 is None and out2 is None
+    gn_defer = ((gn is not None or defer) and can_split and not pw.geglu and res2 is None and out2 is None
                 and out_act == ACT_NONE and post_act == ACT_NONE and alpha == 1.0 and out.dtype == torch.bfloat16
-                and out_ld == pw.N and out_pix_stride == 1 and pw.N % gn[2] == 0 and (pw.N // gn[2]) % 4 == 0
-                and OH * OW * (pw.N // gn[2] // 4) <= 4096)
+                and out_ld == pw.N and out_pix_stride == 1)
+    if gn_defer and gn is not None:
+        gn_defer = pw.N % gn[2] == 0 and (pw.N // gn[2]) % 4 == 0 and OH * OW * (pw.N // gn[2] // 4) <= 4096
+    elif gn_defer:                                         # defer = (channels, groups) of the consuming norm (it may append a skip tensor)
+        ct, ng = defer if isinstance(defer, tuple) else (pw.N, 32)
+        cg = ct // ng
+        gn_defer = ct % ng == 0 and cg % 4 == 0 and pw.N % cg == 0 and OH * OW * (cg // 4) <= 4096
     fast_path = not (pw.Cin % 64 or (x2 is not None and x2.shape[3] % 64) or in_act)
     tuning = False
     if tile == 0 and ring == 0:
@@ -460,7 +493,11 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
 
     def finish():
         # the GroupNorm of gn=: over the partial tiles when the launch deferred its reduce, else over the bf16 output
+        global _PENDING
         if gn is None:
+            if eff > 1:
+                _PENDING = Deferred(out, a.workspace, eff, a.bias, a.rowbias, a.rowbias_ld, a.res, (pw, rowbias, res))
+                return _PENDING
             return out
         gamma, beta, groups, eps, act = gn
         if eff <= 1:
@@ -469,8 +506,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         y = torch.empty(B, OH, OW, pw.N, dtype=torch.bfloat16, device=x.device)
         n = M * pw.N
         check(_launch(f"groupnorm_partials|HW{OH * OW} C{pw.N} S{eff}", 10.0 * n, (4.0 * eff + 2.0) * n, lambda: lib.aldm_groupnorm_partials(
-            a.workspace, eff, B, OH * OW, pw.N, a.bias, a.rowbias, a.rowbias_ld, a.res, (a.out if gn_keep else None), groups, eps,
-            _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm_partials")
+            a.workspace, eff, B, OH * OW, pw.N, a.bias, a.rowbias, a.rowbias_ld, a.res, (a.out if gn_keep else None), None, 0,
+            groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm_partials")
         return (out, y) if gn_keep else y
 
     if tuning and TUNER.slot is not None:                      # stage 2 of the tuner: time this launch in context
@@ -495,6 +532,24 @@ def linear(x2d: torch.Tensor, pw: PackedW, **kw):
 
 
 def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
+    """GroupNorm(+SiLU) over channels-last x (| x2).  x may be a Deferred: its split-K reduce then happens here (and fills x.out)."""
+    global _PENDING
+    if isinstance(x, Deferred):
+        if x is not _PENDING:
+            raise _lib.AldmError("groupnorm: this deferred convolution's partial tiles are gone (not the pending one)")
+        B, H, W, C1 = x.out.shape
+        C2 = x2.shape[3] if x2 is not None else 0
+        Cg = (C1 + C2) // groups
+        if (C1 + C2) % groups or Cg % 4 or C1 % Cg or H * W * (Cg // 4) > 4096:
+            raise _lib.AldmError(f"groupnorm: deferred input [{B} x {H * W} x {C1}+{C2} / {groups} groups] does not fit aldm_groupnorm_partials")
+        y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.out.device)
+        lib = _lib.load()
+        n = B * H * W * (C1 + C2)
+        check(_launch(f"groupnorm_partials|HW{H * W} C{C1}+{C2} S{x.eff}", 10.0 * n, (4.0 * x.eff + 2.0) * n, lambda: lib.aldm_groupnorm_partials(
+            x.ws, x.eff, B, H * W, C1, x.bias, x.rowbias, x.rowbias_ld, x.res, _p(x.out), _p(x2), C2, groups, eps,
+            _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm_partials")
+        _PENDING = None
+        return y
     _require_gpu(x)
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0

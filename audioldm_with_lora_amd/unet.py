@@ -226,10 +226,13 @@ def pack_transformer(t: Transformer2DModel):
 # ----------------------------------------------------------------------------------------------
 # launch sequences
 # ----------------------------------------------------------------------------------------------
-def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None):
+def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=None):
     """ResnetBlock2D over x (| x2).  next_gn = (gamma, beta, groups, eps, act) of a GroupNorm that consumes the block output
-    (the Transformer2DModel behind it): returns (output, its GroupNorm), the norm fused with conv2's split-K reduce."""
+    (the Transformer2DModel behind it): returns (output, its GroupNorm), the norm fused with conv2's split-K reduce.
+    x may be an ops.Deferred (producer's split-K reduce pending): norm1 performs it.  defer = (channels, groups) of the norm
+    that will consume THIS block's output next: conv2 may then return an ops.Deferred in turn."""
     h = ops.groupnorm(x, P.g1, P.b1, P.groups, P.eps, ACT_SILU, x2=x2)
+    x = ops.tensor_of(x)
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
     # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
     h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=(P.g2, P.b2, P.groups, P.eps, ACT_SILU))
@@ -240,7 +243,7 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None):
         xs = x
     if next_gn is not None:
         return ops.conv(h, P.conv2, pad=(1, 1), res=xs, gn=next_gn, gn_keep=True)
-    return ops.conv(h, P.conv2, pad=(1, 1), res=xs)
+    return ops.conv(h, P.conv2, pad=(1, 1), res=xs, defer=(defer or False))
 
 
 def run_attention(P, hn, h_res, B, N, fp8=False):
@@ -257,8 +260,9 @@ def transformer_gn(P):
     return (P.gn_g, P.gn_b, P.groups, 1e-6, ACT_NONE)
 
 
-def run_transformer(P, x, fp8=False, xn=None):
-    """Transformer2DModel over x; xn = its GroupNorm when the producer already computed it (run_resnet next_gn)."""
+def run_transformer(P, x, fp8=False, xn=None, defer=None):
+    """Transformer2DModel over x; xn = its GroupNorm when the producer already computed it (run_resnet next_gn); defer as in
+    run_resnet (the last GEMM may leave its split-K reduce to the next block's norm1)."""
     B, H, W, C = x.shape
     N = H * W
     h = xn if xn is not None else ops.groupnorm(x, *transformer_gn(P))
@@ -268,9 +272,9 @@ def run_transformer(P, x, fp8=False, xn=None):
     h = run_attention(P.attn2, h if P.attn2.ln_folded else ops.layernorm(h, *P.ln[1]), h, B, N, fp8)   # encoder_hidden_states=None: self-attention
     g = ops.linear(h if P.ff1.ln_s is not None else ops.layernorm(h, *P.ln[2]), P.ff1)
     if P.ff2_proj is not None:                                # ff2 and proj_out as ONE GEMM over the virtual concat [g | h]
-        return ops.conv(g.view(B, H, W, 4 * C), P.ff2_proj, x2=h.view(B, H, W, C), res=x)
+        return ops.conv(g.view(B, H, W, 4 * C), P.ff2_proj, x2=h.view(B, H, W, C), res=x, defer=(defer or False))
     h = ops.linear(g, P.ff2, res=h)
-    return ops.conv(h.view(B, H, W, C), P.proj_out, res=x)
+    return ops.conv(h.view(B, H, W, C), P.proj_out, res=x, defer=(defer or False))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -431,33 +435,52 @@ class UNet2DConditionModel(nn.Module):
 
         h = ops.conv(x, P.conv_in, pad=(1, 1))
         skips = [h]
-        for blk in P.down:
+        # `nxt` = (channels, groups) of the GroupNorm that consumes a block's output next (norm1 of the following ResnetBlock2D,
+        # over torch.cat([h, skip]) on the way up): a split-K producer then leaves its reduce to that norm (ops.Deferred)
+        def norm1_of(r):
+            return (r.g1.numel(), r.groups)
+
+        for bi, blk in enumerate(P.down):
+            nr = len(blk.resnets)
             for i, r in enumerate(blk.resnets):
+                if i + 1 < nr:
+                    nxt = norm1_of(blk.resnets[i + 1])
+                elif blk.down is not None:
+                    nxt = None                                        # a down-sampling conv follows
+                else:
+                    nxt = norm1_of(P.mid.resnets[0])
                 if blk.attns is not None:
                     h, hn = run_resnet(r, h, None, rowbias, ld, next_gn=transformer_gn(blk.attns[i]))
-                    h = run_transformer(blk.attns[i], h, fp8, xn=hn)
+                    h = run_transformer(blk.attns[i], h, fp8, xn=hn, defer=nxt)
                 else:
-                    h = run_resnet(r, h, None, rowbias, ld)
-                skips.append(h)
+                    h = run_resnet(r, h, None, rowbias, ld, defer=nxt)
+                skips.append(ops.tensor_of(h))
             if blk.down is not None:
-                h = ops.conv(h, blk.down, stride=(2, 2), pad=(1, 1))
-                skips.append(h)
+                h = ops.conv(h, blk.down, stride=(2, 2), pad=(1, 1), defer=norm1_of(P.down[bi + 1].resnets[0]))
+                skips.append(ops.tensor_of(h))
         h, hn = run_resnet(P.mid.resnets[0], h, None, rowbias, ld, next_gn=transformer_gn(P.mid.attns[0]))
-        h = run_transformer(P.mid.attns[0], h, fp8, xn=hn)
-        h = run_resnet(P.mid.resnets[1], h, None, rowbias, ld)
+        h = run_transformer(P.mid.attns[0], h, fp8, xn=hn, defer=norm1_of(P.mid.resnets[1]))
+        h = run_resnet(P.mid.resnets[1], h, None, rowbias, ld, defer=norm1_of(P.up[0].resnets[0]))
         for bi, blk in enumerate(P.up):
+            nr = len(blk.resnets)
             for i, r in enumerate(blk.resnets):
+                if i + 1 < nr:
+                    nxt = norm1_of(blk.resnets[i + 1])
+                elif blk.up is not None:
+                    nxt = None                                        # the up-sampling conv follows
+                else:
+                    nxt = (P.gn_out[0].numel(), groups)               # conv_norm_out
                 if blk.attns is not None:
                     h, hn = run_resnet(r, h, skips.pop(), rowbias, ld, next_gn=transformer_gn(blk.attns[i]))
-                    h = run_transformer(blk.attns[i], h, fp8, xn=hn)
+                    h = run_transformer(blk.attns[i], h, fp8, xn=hn, defer=nxt)
                 else:
-                    h = run_resnet(r, h, skips.pop(), rowbias, ld)
+                    h = run_resnet(r, h, skips.pop(), rowbias, ld, defer=nxt)
             if blk.up is not None:
                 if forward_upsample_size:
                     size = (skips[-1].shape[1], skips[-1].shape[2])
                 else:
                     size = (h.shape[1] * 2, h.shape[2] * 2)
-                h = ops.conv(h, blk.up, pad=(1, 1), up_size=size)
+                h = ops.conv(h, blk.up, pad=(1, 1), up_size=size, defer=norm1_of(P.up[bi + 1].resnets[0]))
         h = ops.groupnorm(h, P.gn_out[0], P.gn_out[1], groups, eps, ACT_SILU)
         return ops.conv(h, P.conv_out, pad=(1, 1), out_f32=True)
 

@@ -125,10 +125,13 @@ int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float*
    (ws fp32 [splits][B*HW][C], as left by aldm_igemm with defer_reduce; bias / rowbias / res may be NULL).  Fuses the split-K
    reduce of ResnetBlock2D.conv1 (bias + time-embedding projection) with norm2 + SiLU, and that of conv2 (bias + shortcut
    residual `res`, bf16 [B*HW][C]) with the norm of the Transformer2DModel that follows: one launch instead of two.
-   sum_out (bf16 [B*HW][C], may be NULL) receives x itself -- the block output the residual stream carries on. */
+   sum_out (bf16 [B*HW][C], may be NULL) receives x itself -- the block output the residual stream carries on.
+   x2 (bf16 [B*HW][C2], may be NULL with C2 = 0) appends C2 plain channels: the norm then runs over torch.cat([x, x2]) as
+   norm1 of an up-block ResnetBlock2D does (gamma / beta / y have C + C2 channels; the group width must divide C). */
 int aldm_groupnorm_partials(const float* ws, int splits, int B, int HW, int C, const float* bias, const float* rowbias,
-                            int rowbias_ld, const void* res, void* sum_out, int groups, float eps, const float* gamma,
-                            const float* beta, int act, void* y, void* stream);
+                            int rowbias_ld, const void* res, void* sum_out, const void* x2, int C2, int groups, float eps,
+                            const float* gamma, const float* beta, int act, void* y,
+                            void* stream);
 /* ClapTextEmbeddings: y[b*L+j] = LayerNorm(word[ids[b][j]] + type0 + pos[pid]) as bf16 [B*L][C]; pid counts the non-pad
    tokens up to and including j (offset by pad_idx; pad tokens use pid = pad_idx).  ids int64 on the device, fp32 tables.
    First op of `text_encoder(input_ids, attention_mask)` [REF script/train/train_audioldm_lora.py:513-518]. */

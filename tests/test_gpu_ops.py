@@ -159,6 +159,39 @@ def test_conv_groupnorm_over_split_partials(ops, B, C, Cout, H, W, groups, split
     close(to_nchw(yn), want_n, rtol=1.5e-2)
 
 
+@pytest.mark.parametrize("B,C,Cout,C2,H,W,groups,splits", [
+    (8, 128, 640, 384, 16, 4, 32, 4),     # up-block norm1 over cat([h, skip]): 32-channel groups, 20 in h and 12 in the skip
+    (2, 64, 384, 0, 63, 4, 32, 3),        # down path: no skip
+    (2, 64, 128, 128, 25, 16, 32, 2),     # group width 8
+])
+def test_conv_deferred_reduce_consumed_by_next_groupnorm(ops, B, C, Cout, C2, H, W, groups, splits):
+    """conv(defer=...) hands its split-K partial tiles to the NEXT groupnorm(), which also fills the conv's bf16 output"""
+    g = torch.Generator().manual_seed(19)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = bf(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b = torch.randn(Cout, generator=g)
+    r = bf(torch.randn(B, Cout, H, W, generator=g))
+    skip = bf(torch.randn(B, C2, H, W, generator=g) * 1.5 + 0.3) if C2 else None
+    gamma, beta = torch.randn(Cout + C2, generator=g), torch.randn(Cout + C2, generator=g)
+    want_h = F.conv2d(x, w, b, padding=1) + r
+    cat = torch.cat([bf(want_h), skip], 1) if C2 else want_h
+    want_n = F.silu(F.group_norm(cat, groups, gamma, beta, 1e-5))
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    d = ops.conv(nhwc(x), pw, pad=(1, 1), res=nhwc(r), splits=splits, defer=(Cout + C2, groups))
+    assert isinstance(d, ops.Deferred) and d.eff > 1
+    from audioldm_with_lora_amd._lib import AldmError
+    with pytest.raises(AldmError):                           # the workspace is taken until the consumer norm has run
+        ops.conv(nhwc(x), pw, pad=(1, 1))
+    y = ops.groupnorm(d, gamma.to(DEV), beta.to(DEV), groups, 1e-5, ops.ACT_SILU, x2=(nhwc(skip) if C2 else None))
+    close(to_nchw(ops.tensor_of(d)), want_h)
+    close(to_nchw(y), want_n, rtol=1.5e-2)
+    with pytest.raises(AldmError):                           # consumed: the handle is dead
+        ops.groupnorm(d, gamma.to(DEV), beta.to(DEV), groups, 1e-5)
+    # a shape the fused norm cannot take (group width does not divide the conv's channels) is not deferred
+    t = ops.conv(nhwc(x), pw, pad=(1, 1), splits=splits, defer=(Cout + 16, 4 * groups if (Cout + 16) % (4 * groups) == 0 else groups + 1))
+    assert torch.is_tensor(t)
+
+
 def test_conv_two_sources_rowbias_residual_f32out(ops):
     g = torch.Generator().manual_seed(2)
     x1 = bf(torch.randn(2, 96, 10, 8, generator=g))
