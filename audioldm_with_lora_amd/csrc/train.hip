@@ -36,7 +36,10 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
                                                                    int groups, float eps, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
                                                                    bf16* __restrict__ dx, bf16* __restrict__ dx2,
-                                                                   const bf16* dx_acc, const bf16* dx2_acc, AldmDiv dqpp) {
+                                                                   const bf16* dx_acc, const bf16* dx2_acc, AldmDiv dqpp,
+                                                                   const float* __restrict__ dy_ws, int dy_splits, long long dy_sstride) {
+  // dy_ws: dY still as the split-K partial tiles [dy_splits][B*HW][C] (fp32) of the dX convolution that produced it
+  // (aldm_igemm defer_reduce): summed here in split order and rounded to bf16, exactly what igemm_reduce_kernel would store
   __shared__ float red[16];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -57,7 +60,23 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
       const int c = c0 + 4 * j;
       t = (c < C1) ? *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c)
                    : *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
-      u = *reinterpret_cast<const bf16x4*>(dy + ((long long)b * HW + pix) * C + c);
+      const long long doff = ((long long)b * HW + pix) * C + c;
+      if (dy_ws) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        const float* w0 = dy_ws + doff;
+        int sp = 0;
+        for (; sp + 4 <= dy_splits; sp += 4) {               // four partials in flight per trip, summed in split order
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(w0 + sp * dy_sstride), a1 = *reinterpret_cast<const f32x4*>(w0 + (sp + 1) * dy_sstride);
+          const f32x4 a2 = *reinterpret_cast<const f32x4*>(w0 + (sp + 2) * dy_sstride), a3 = *reinterpret_cast<const f32x4*>(w0 + (sp + 3) * dy_sstride);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[k] = (((a[k] + a0[k]) + a1[k]) + a2[k]) + a3[k];
+        }
+        for (; sp < dy_splits; ++sp) a += *reinterpret_cast<const f32x4*>(w0 + sp * dy_sstride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = (bf16)a[k];
+      } else {
+        u = *reinterpret_cast<const bf16x4*>(dy + doff);
+      }
     }
     v[i] = t;
     d[i] = u;
@@ -534,10 +553,10 @@ inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / p
 
 }  // namespace
 
-extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
-                                  float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2,
-                                  const void* dx_acc, const void* dx2_acc, void* stream) {
-  ALDM_CHECK_ARG(x && dy && dx && gamma && beta && B > 0 && HW > 0, "groupnorm_bwd: bad args");
+static int groupnorm_bwd_impl(const void* x, const void* x2, const void* dy, const float* dy_ws, int dy_splits, int B, int HW,
+                              int C1, int C2, int groups, float eps, const float* gamma, const float* beta, int act, void* dx,
+                              void* dx2, const void* dx_acc, const void* dx2_acc, void* stream) {
+  ALDM_CHECK_ARG(x && (dy || (dy_ws && dy_splits >= 1)) && dx && gamma && beta && B > 0 && HW > 0, "groupnorm_bwd: bad args");
   const int C = C1 + C2;
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0 && (C2 == 0 || x2), "groupnorm_bwd: bad channels");
   const long long nquads = (long long)HW * (C / groups / 4);
@@ -546,13 +565,28 @@ extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy,
 #define ALDM_GNB(QPT)                                                                                                  \
   hipLaunchKernelGGL(groupnorm_bwd_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
                      (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
-                     (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc, dq)
+                     (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc, dq, dy_ws, dy_splits,           \
+                     (long long)B * HW * C)
   if (nquads <= 4 * GN_THREADS) ALDM_GNB(4);
   else if (nquads <= 8 * GN_THREADS) ALDM_GNB(8);
   else if (nquads <= 16 * GN_THREADS) ALDM_GNB(16);
   else ALDM_GNB(32);
 #undef ALDM_GNB
   return aldm_launch_status("groupnorm_bwd");
+}
+
+extern "C" int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
+                                  float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2,
+                                  const void* dx_acc, const void* dx2_acc, void* stream) {
+  return groupnorm_bwd_impl(x, x2, dy, nullptr, 0, B, HW, C1, C2, groups, eps, gamma, beta, act, dx, dx2, dx_acc, dx2_acc, stream);
+}
+
+extern "C" int aldm_groupnorm_bwd_partials(const void* x, const void* x2, const float* dy_ws, int dy_splits, int B, int HW, int C1,
+                                           int C2, int groups, float eps, const float* gamma, const float* beta, int act,
+                                           void* dx, void* dx2, const void* dx_acc, const void* dx2_acc, void* stream) {
+  ALDM_CHECK_ARG(dy_ws && dy_splits >= 1, "groupnorm_bwd_partials: null workspace / bad splits");
+  return groupnorm_bwd_impl(x, x2, nullptr, dy_ws, dy_splits, B, HW, C1, C2, groups, eps, gamma, beta, act, dx, dx2, dx_acc, dx2_acc,
+                            stream);
 }
 
 extern "C" int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx,

@@ -739,12 +739,21 @@ def _like(buf, like):
 def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True, dx_add=None, dx2_add=None):
     """dx (dx2) of act(group_norm(cat[x, x2])).  dx_add / dx2_add: gradients x / x2 already hold from their other consumers;
     they are added inside the kernel (fresh output tensors, the inputs are not modified)."""
+    global _PENDING
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
     dx = torch.empty_like(x)
     dx2 = torch.empty_like(x2) if (x2 is not None and need_dx2) else None
     a1 = _like(dx_add, x) if dx_add is not None else None
     a2 = _like(dx2_add, x2) if (dx2 is not None and dx2_add is not None) else None
+    if isinstance(dy, Deferred):                           # dY = partial tiles of the dX convolution launched just before
+        if dy is not _PENDING or dy.bias is not None or dy.rowbias is not None or dy.res is not None:
+            raise _lib.AldmError("groupnorm_bwd: deferred dY must be the pending split-K launch, without bias / residual")
+        assert tuple(dy.out.shape) == (B, H, W, C1 + C2)
+        check(_lib.load().aldm_groupnorm_bwd_partials(_p(x), _p(x2), dy.ws, dy.eff, B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta),
+                                                      act, _p(dx), _p(dx2), _p(a1), _p(a2), _stream()), "aldm_groupnorm_bwd_partials")
+        _PENDING = None
+        return dx, dx2
     check(_lib.load().aldm_groupnorm_bwd(_p(x), _p(x2), _p(dy), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act,
                                          _p(dx), _p(dx2), _p(a1), _p(a2), _stream()), "aldm_groupnorm_bwd")
     return dx, dx2

@@ -35,10 +35,12 @@ BK = 64
 # tape
 # ----------------------------------------------------------------------------------------------
 class Var:
-    __slots__ = ("t", "g", "rg")
+    __slots__ = ("t", "g", "rg", "gn")
 
     def __init__(self, t, rg=False):
         self.t, self.g, self.rg = t, None, rg
+        self.gn = None               # (channels, groups) when this is a GroupNorm output: its single consumer conv may hand the
+                                     # norm's backward its dX as split-K partial tiles (g is then an ops.Deferred)
 
     @property
     def shape(self):
@@ -127,6 +129,9 @@ def t_conv(tape, x, pw, x2=None, stride=(1, 1), pad=(0, 0), up_size=None, rowbia
                 acc(src, ops.upsample_nearest_bwd(ops.conv(dy, bw, pad=bpad), ih, iw))
             elif stride == (2, 2):
                 put(src, ops.conv(dy, bw, pad=bpad, in_dilate=2, out_hw=(ih, iw), res=prior(src, src.t)))
+            elif src.gn is not None and x2 is None and src.g is None:
+                # the input is a GroupNorm output: its backward is the next closure on the tape and sums the partial tiles
+                put(src, ops.conv(dy, bw, pad=bpad, defer=src.gn))
             else:
                 put(src, ops.conv(dy, bw, pad=bpad, res=prior(src, src.t)))
     tape.record(bwd)
@@ -145,6 +150,8 @@ def t_groupnorm(tape, x, gamma, beta, groups, eps, act, x2=None, fwd=None):
     y = Var(fwd if fwd is not None else ops.groupnorm(x.t, gamma, beta, groups, eps, act, x2=(x2.t if x2 is not None else None)))
     y.rg = x.rg or (x2 is not None and x2.rg)
     if y.rg:
+        y.gn = (y.t.shape[3], groups)
+
         def bwd():
             if y.g is None:
                 return
@@ -394,10 +401,13 @@ class LoraTrainer:
     @staticmethod
     def _resnet(tape, Pr, x, x2, rowbias, ld, next_gn=None):
         """next_gn: GroupNorm of the Transformer2DModel behind the block -> returns (output, its norm) as unet.run_resnet"""
+        # the shortcut is recorded FIRST: on the way back every conv's dX is then followed directly by the backward of the
+        # GroupNorm that produced its input (conv2 -> norm2 -> conv1 -> norm1 -> shortcut), which lets a split-K dX conv leave
+        # its reduce to that norm (t_conv / ops.groupnorm_bwd with an ops.Deferred)
+        xs = t_conv(tape, x, Pr.shortcut, x2=x2) if Pr.shortcut is not None else x
         h = t_groupnorm(tape, x, Pr.g1, Pr.b1, Pr.groups, Pr.eps, ACT_SILU, x2=x2)
         _, h = t_conv_gn(tape, h, Pr.conv1, (Pr.g2, Pr.b2, Pr.groups, Pr.eps, ACT_SILU), pad=(1, 1),
                          rowbias=rowbias[:, Pr.temb_off:], rowbias_ld=ld)
-        xs = t_conv(tape, x, Pr.shortcut, x2=x2) if Pr.shortcut is not None else x
         if next_gn is not None:
             return t_conv_gn(tape, h, Pr.conv2, next_gn, pad=(1, 1), res=xs)
         return t_conv(tape, h, Pr.conv2, pad=(1, 1), res=xs)

@@ -226,6 +226,11 @@ int aldm_add_noise(const float* x, const float* noise, const float* coef, int B,
 int aldm_groupnorm_bwd(const void* x, const void* x2, const void* dy, int B, int HW, int C1, int C2, int groups,
                        float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2, const void* dx_acc,
                        const void* dx2_acc, void* stream);
+/* the same with dY still as the fp32 split-K partial tiles [dy_splits][B*HW][C1+C2] of the dX convolution that produced it
+   (aldm_igemm with defer_reduce, no bias / residual): the reduce launch of that convolution disappears */
+int aldm_groupnorm_bwd_partials(const void* x, const void* x2, const float* dy_ws, int dy_splits, int B, int HW, int C1, int C2,
+                                int groups, float eps, const float* gamma, const float* beta, int act, void* dx, void* dx2,
+                                const void* dx_acc, const void* dx2_acc, void* stream);
 int aldm_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, void* dx, const void* dx_acc,
                        void* stream);
 /* GEGLU on the interleaved (16 value | 16 gate) projection h [M][2I]: out [M][I] = value * gelu(gate), and its backward */

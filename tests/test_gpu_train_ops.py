@@ -250,3 +250,26 @@ def test_tn_batched_many_jobs_one_launch(ops):
     assert not tb.jobs[32] and not tb.jobs[64] and not tb.keep
     for flat, want in zip(outs, wants):
         close(flat.cpu().view(want.shape), want, rtol=1e-3, atol=2e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,splits,act", [(8, 640, 0, 640, 16, 4, 6, 1), (2, 256, 128, 384, 63, 4, 3, 1), (2, 128, 0, 64, 25, 16, 2, 0)])
+def test_groupnorm_bwd_takes_dy_as_split_partials(B, C1, C2, Cout, H, W, splits, act):
+    """dX conv with defer -> groupnorm_bwd sums the partial tiles: bit-identical to reduce launch + groupnorm_bwd"""
+    from audioldm_with_lora_amd import ops
+    g = torch.Generator().manual_seed(23)
+    C = C1 + C2
+    x = (torch.randn(B, H, W, C1, generator=g) * 1.5 + 0.2).to(torch.bfloat16).cuda()
+    x2 = (torch.randn(B, H, W, C2, generator=g)).to(torch.bfloat16).cuda() if C2 else None
+    gm, bt = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    dyo = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).cuda()              # gradient of the conv's OUTPUT
+    wt = (torch.randn(C, Cout, 3, 3, generator=g) / (3 * Cout ** 0.5)).cuda()            # transposed filter of the dX conv
+    pw = ops.pack_conv(wt, None)
+    ref_dy = ops.conv(dyo, pw, pad=(1, 1), splits=splits)
+    want = ops.groupnorm_bwd(x, ref_dy, gm, bt, 32, 1e-5, act, x2=x2)
+    d = ops.conv(dyo, pw, pad=(1, 1), splits=splits, defer=(C, 32))
+    assert isinstance(d, ops.Deferred)
+    got = ops.groupnorm_bwd(x, d, gm, bt, 32, 1e-5, act, x2=x2)
+    assert torch.equal(got[0], want[0])
+    if C2:
+        assert torch.equal(got[1], want[1])
+    assert ops._PENDING is None
