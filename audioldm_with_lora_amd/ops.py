@@ -361,6 +361,12 @@ class Deferred:
 _PENDING = None                                            # the Deferred whose partial tiles currently own the workspace
 
 
+def drop_pending():
+    """Forget a deferred reduce nobody consumed (an exception between producer and consumer): called at the top of a forward."""
+    global _PENDING
+    _PENDING = None
+
+
 def tensor_of(x):
     """the bf16 tensor behind a conv result (for a Deferred: valid on the stream once its consumer norm has been launched)"""
     return x.out if isinstance(x, Deferred) else x

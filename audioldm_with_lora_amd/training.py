@@ -413,6 +413,7 @@ class LoraTrainer:
         return t_conv(tape, h, Pr.conv2, pad=(1, 1), res=xs)
 
     def forward(self, tape, x_in, t_dev, cls_bf16):
+        ops.drop_pending()
         u, P = self.unet, self.P
         cfg = u.cfg
         b, H, W, _ = x_in.shape

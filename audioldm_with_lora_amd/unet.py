@@ -414,6 +414,7 @@ class UNet2DConditionModel(nn.Module):
         """x [b, H, W, Cin] bf16 channels-last, t_dev fp32 [1] or [b] (device), class_labels [b, D] bf16.
         rowbias: optional precomputed time-embedding projections [b, temb_total] fp32 (temb_table); t_dev / class_labels are
         then unused.  Returns eps fp32 [b, H, W, Cout]."""
+        ops.drop_pending()
         cfg, P = self.cfg, self.plan()
         fp8 = bool(getattr(self, "attention_fp8", False))       # BASELINE config 5: e4m3 Q / K / V / P attention operands
         b, H, W, _ = x.shape
