@@ -309,12 +309,9 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, 
   auto kern = attention_kernel<DP, NW, SP>;
   constexpr int LDS = 2 * SP * Cfg::TILE;
   static_assert(SP == 1 || (SP - 1) * (NW / SP) * (Cfg::DT * 16 + 2) * 256 <= LDS, "merge buffer must fit the staging area");
-  static bool attr_done = false;
-  if (!attr_done && LDS > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { aldm_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
-  attr_done = true;
+  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
+  if (LDS > 48 * 1024)
+    if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), LDS, &attr_done, "attention")) return rc;
   dim3 grid(cdiv(N, 32 * (NW / SP)), H, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt,
                      vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld, lse, kv_len);

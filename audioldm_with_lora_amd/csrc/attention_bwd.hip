@@ -308,12 +308,9 @@ int launch_bwd(const void* q, const void* k, const void* v, int ld, const void* 
   constexpr int lds_b = 2 * Cfg::RBYTES + 2 * Cfg::TBYTES + 2 * TS * 4;
   auto ka = attn_bwd_dq_kernel<DP, NW>;
   auto kb = attn_bwd_dkv_kernel<DP, NW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
-    attr_done = true;
-  }
+  static unsigned long long done_a = 0, done_b = 0;   // per-device bit masks (aldm_set_max_lds)
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(ka), lds_a, &done_a, "attention_bwd dq")) return rc;
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kb), lds_b, &done_b, "attention_bwd dkv")) return rc;
   dim3 grid(cdiv(N, 32 * NW), H, B);
   hipLaunchKernelGGL(ka, grid, dim3(64 * NW), lds_a, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, ld, (const bf16*)kT,
                      ldt, kt_bs, (const bf16*)dO, (const bf16*)O, ldo, lse, delta, N, D, scale, (bf16*)dq, ldg);

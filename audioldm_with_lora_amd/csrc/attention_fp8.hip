@@ -242,12 +242,9 @@ int launch8(const void* q, int ldq, const void* k, int ldk, const void* vt, int 
             float scale, void* out, int out_ld, hipStream_t st) {
   using C8 = Cfg8<DP>;
   auto kern = attention_fp8_kernel<DP, NW>;
-  static bool attr_done = false;
-  if (!attr_done && C8::LDS > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C8::LDS);
-    if (e != hipSuccess) { aldm_set_error("attention_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
-  attr_done = true;
+  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
+  if (C8::LDS > 48 * 1024)
+    if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), C8::LDS, &attr_done, "attention_fp8")) return rc;
   hipLaunchKernelGGL(kern, dim3(cdiv(N, 32 * NW), H, B), dim3(64 * NW), C8::LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk,
                      (const bf16*)vt, vt_ld, vt_bs, N, D, scale * 1.44269504088896340736f, (bf16*)out, out_ld);
   return aldm_launch_status("attention_fp8");

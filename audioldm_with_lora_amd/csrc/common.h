@@ -33,6 +33,22 @@ static inline int aldm_launch_status(const char* what) {
   return ALDM_OK;
 }
 
+// One-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) per kernel AND per device: the attribute lives with the device's
+// copy of the code object, so a process that launches on a second GPU must set it there too.  `done` is the call site's static
+// bit mask (bit = device ordinal; ordinals >= 64 set the attribute on every call, which is merely slower).
+static inline int aldm_set_max_lds(const void* kern, int bytes, unsigned long long* done, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+  if (dev < 64 && ((*done >> dev) & 1ull)) return ALDM_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    aldm_set_error("%s: hipFuncSetAttribute(%d B of LDS): %s", what, bytes, hipGetErrorString(e));
+    return (int)e;
+  }
+  if (dev < 64) *done |= 1ull << dev;
+  return ALDM_OK;
+}
+
 // n / d for a launch-constant d (round-up magic number, exact for 0 <= n < 2^31): a hardware integer division is ~40 instructions
 struct AldmDiv { unsigned mul, shift; };
 __device__ __forceinline__ int aldm_div(int n, AldmDiv d) {

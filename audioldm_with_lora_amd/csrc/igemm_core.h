@@ -1124,15 +1124,11 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   // S == 0: register-staged double buffer (needed when the gather applies an activation); else LDS-DMA ring
   constexpr size_t lds_loop = (S == 0 ? 2 : S) * (size_t)(BM + BN + RP) * 128 + ((S != 0 && RP > 0) ? (size_t)BN * 128 : 0);
   constexpr size_t lds = (lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES) + 2 * BM * sizeof(float);
-  static bool attr_done = false;   // one-time, idempotent; races are benign
+  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds); one-time, idempotent, races are benign
   void (*kern)(const IgemmDev);
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
   else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S, EPI>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { aldm_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm")) return rc;
   if (VT && d.vt_col0 % BN != 0) {
     aldm_set_error("igemm: vt_col0 %d must be a multiple of the tile width %d", d.vt_col0, BN);
     return ALDM_E_ARG;

@@ -192,13 +192,9 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128;
   constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
   auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, LEAN>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { aldm_set_error("igemm_halo: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_halo")) return rc;
   const int rows_pt = BM / d.OW;
   if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
     aldm_set_error("igemm_halo: image width %d does not fit the %dx%d halo tile", d.OW, BM, BN);

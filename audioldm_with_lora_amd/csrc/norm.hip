@@ -406,12 +406,8 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0, "groupnorm: group width %d / C1 %d must be multiples of 4", C / groups, C1);
   ALDM_CHECK_ARG(C2 == 0 || x2, "groupnorm: C2 without x2");
   const size_t lds = (size_t)GN_LDS_QUADS * 8 + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(groupnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { aldm_set_error("groupnorm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(groupnorm_kernel), (int)lds, &attr_done, "groupnorm")) return rc;
   const long long nquads = (long long)HW * (C / groups / 4);
   const AldmDiv dq = aldm_make_div((unsigned)(C / groups / 4));
 #define ALDM_GN_REG(QPT)                                                                                               \

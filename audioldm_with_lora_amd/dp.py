@@ -2,16 +2,20 @@
 
 Mirrors the slice of `accelerate.Accelerator` the reference trainer touches
   [REF script/train/train_audioldm_lora.py:327-332,445-447,494,551,557-561,576,615]:
-  prepare / accumulate / backward / gather / sync_gradients / is_main_process / wait_for_everyone / save_state /
-  unwrap_model / device / num_processes.
+  init_trackers / prepare / accumulate / backward / clip_grad_norm_ / gather / sync_gradients / log / is_main_process /
+  wait_for_everyone / save_state / unwrap_model / end_training / device / num_processes, plus `ProjectConfiguration`.
 The reference's DDP traffic collapses to:
   C1  gradient all-reduce  -> ONE all-reduce of the flat fp32 LoRA gradient buffer (<= 7.2 MB at r = 16)
   C2  loss all_gather      -> rides in the extra last slot of the same buffer
   C3  initial broadcast    -> broadcast of the flat LoRA parameter buffer only (base weights load identically per rank)
   C4  barrier              -> dist.barrier
 """
+import json
 import os
+import time
 from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Optional
 
 import torch
 import torch.distributed as dist
@@ -52,12 +56,36 @@ def shard_batch(n, rank, world):
     return slice(rank * per, (rank + 1) * per)
 
 
+@dataclass
+class ProjectConfiguration:
+    """accelerate.utils.ProjectConfiguration as the reference builds it [REF train:325]."""
+    project_dir: Optional[str] = None
+    logging_dir: Optional[str] = None
+
+    def __post_init__(self):
+        if self.logging_dir is None:
+            self.logging_dir = self.project_dir
+
+
+def _inner_unet(model):
+    """PeftModel -> the wrapped UNet (the object that owns the training engine); anything else unchanged."""
+    return getattr(getattr(model, "base_model", None), "model", model)
+
+
 class Accelerator:
-    """accelerate-shaped facade over torch.distributed for the HIP trainer."""
+    """accelerate-shaped facade over torch.distributed for the HIP trainer.
+
+    Two ways to drive a step:
+      * the reference's own loop body [REF train:539-565]: `unet(...)[0]` -> `F.mse_loss` -> `accelerator.backward(loss)` ->
+        `optimizer.step()` (optim.AdamW) -- `backward` runs autograd (the HIP launch tape behind training._UNetTrainFn) and then
+        ONE all-reduce of the flat LoRA gradient buffer of every prepared model;
+      * `training.LoraTrainer.step(...)`: the same arithmetic as one captured hipGraph + one all-reduce + the flat AdamW."""
 
     def __init__(self, gradient_accumulation_steps=1, mixed_precision=None, log_with=None, project_config=None):
         if gradient_accumulation_steps != 1:
             raise NotImplementedError("the reference trains with gradient_accumulation_steps=1")
+        if mixed_precision not in (None, "no"):
+            raise NotImplementedError("the reference trains with mixed_precision=None [REF train:329]")
         init_from_env()
         self.distributed = dist.is_available() and dist.is_initialized()
         self.num_processes = dist.get_world_size() if self.distributed else 1
@@ -66,6 +94,11 @@ class Accelerator:
         self.device = torch.device("cuda", self.local_process_index) if torch.cuda.is_available() else torch.device("cpu")
         self.sync_gradients = True
         self.gradient_accumulation_steps = 1
+        self.log_with = log_with                      # "wandb" in the reference; here every tracker is a JSONL file
+        self.project_config = project_config or ProjectConfiguration()
+        self._models, self._optimizers, self._schedulers = [], [], []
+        self._log_file = None
+        self._log_path = None
 
     @property
     def is_main_process(self):
@@ -75,19 +108,81 @@ class Accelerator:
     def is_local_main_process(self):
         return self.local_process_index == 0
 
+    # ---- tracking (wandb in the reference [REF train:333-346,570,583-589]; JSONL here: no network) ----
+    def init_trackers(self, project_name, config=None, init_kwargs=None):
+        if not self.is_main_process:
+            return
+        d = self.project_config.logging_dir or "."
+        os.makedirs(d, exist_ok=True)
+        self._log_path = os.path.join(d, f"{project_name}.metrics.jsonl")
+        self._log_file = open(self._log_path, "a")
+        run = (init_kwargs or {}).get("wandb", {})
+        self._log_file.write(json.dumps({"event": "init", "project": project_name, "time": time.time(),
+                                         "run": {k: run[k] for k in run if isinstance(run[k], (str, int, float, list))}}) + "\n")
+        self._log_file.flush()
+
+    def log(self, values, step=None):
+        if not self.is_main_process or self._log_file is None:
+            return
+        rec = {"step": step}
+        for k, v in values.items():
+            rec[k] = float(v) if isinstance(v, (int, float)) or (torch.is_tensor(v) and v.numel() == 1) else str(v)
+        self._log_file.write(json.dumps(rec) + "\n")
+        self._log_file.flush()
+
+    # ---- model / optimiser plumbing ----
     def prepare(self, *objs):
+        """Registers what the loop will use.  A LoRA-wrapped UNet gets its training engine here: the LoRA parameters move into
+        one flat fp32 buffer and rank 0's copy is broadcast (DDP's constructor broadcast, C3, LoRA buffer only)."""
+        from . import optim
+        for o in objs:
+            inner = _inner_unet(o)
+            if isinstance(o, torch.nn.Module) and hasattr(inner, "_has_trainable_lora") and inner._has_trainable_lora():
+                if inner.conv_in.weight.is_cuda:
+                    from .training import trainer_of
+                    trainer_of(inner)
+                self._models.append(o)
+            elif isinstance(o, optim.AdamW):
+                self._optimizers.append(o)
+            elif isinstance(o, optim.PolynomialLR):
+                self._schedulers.append(o)
         return objs if len(objs) != 1 else objs[0]
 
     def unwrap_model(self, model):
-        return getattr(getattr(model, "base_model", None), "model", model)
+        """accelerate strips only the distributed wrapper (`.module`); a PeftModel stays a PeftModel [REF train:347-350,577,598]."""
+        return getattr(model, "module", model)
 
     @contextmanager
     def accumulate(self, model):
         yield
 
+    def backward(self, loss, **kw):
+        """[REF train:557]: autograd backward, then DDP's gradient all-reduce -- one collective per prepared model."""
+        loss.backward(**kw)
+        from .training import trainer_of
+        for m in self._models:
+            tr = trainer_of(_inner_unet(m), create=False)
+            if tr is not None:
+                tr.allreduce_grads_()
+
+    def clip_grad_norm_(self, parameters, max_norm, norm_type=2):
+        """[REF train:559-561].  In the reference `parameters` is an already-exhausted iterator, so the call clips nothing
+        (SURVEY.md quirk Q1); with a real parameter list this clips the gradients in place like torch's utility."""
+        params = [p for p in parameters if getattr(p, "grad", None) is not None]
+        if not params:
+            return torch.zeros((), device=self.device)
+        if norm_type != 2:
+            raise NotImplementedError("only the 2-norm is implemented")
+        total = torch.sqrt(sum((p.grad.detach().float() ** 2).sum() for p in params))
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for p in params:
+            p.grad.mul_(coef)
+        return total
+
     def gather(self, t):
         if not self.distributed or self.num_processes == 1:
             return t.reshape(1) if t.dim() == 0 else t
+        t = t.detach()
         out = [torch.empty_like(t) for _ in range(self.num_processes)]
         dist.all_gather(out, t)
         return torch.stack(out) if t.dim() == 0 else torch.cat(out)
@@ -97,17 +192,32 @@ class Accelerator:
             dist.barrier()
 
     def save_state(self, output_dir, trainer=None):
-        """LoRA-only checkpoint (what the reference evidently intended): adapter weights as
-        safetensors with peft key names + flat optimiser state."""
-        if not self.is_main_process or trainer is None:
+        """[REF train:574-576] `accelerator.save_state(save_path)`: LoRA-only `model.safetensors` with peft key names (what the
+        reference evidently intended) + `optimizer.bin` + `scheduler.bin`.  Takes the models /
+        optimisers registered by prepare(); `trainer=` adds a LoraTrainer (the fast path keeps its moments there)."""
+        if not self.is_main_process:
             return
+        models = [_inner_unet(m) for m in self._models]
+        if trainer is not None and all(trainer.unet is not m for m in models):
+            models.append(trainer.unet)
+        if not models:
+            raise RuntimeError("Accelerator.save_state: nothing to save -- pass the model through accelerator.prepare(...) first "
+                               "(or give save_state the LoraTrainer)")
         from safetensors.torch import save_file
         os.makedirs(output_dir, exist_ok=True)
-        sd = {("base_model.model." + n): p.detach().float().cpu().contiguous()
-              for n, p in trainer.unet.named_parameters() if "lora_" in n}
-        save_file(sd, os.path.join(output_dir, "model.safetensors"))
-        torch.save({"m": trainer.flat.m.cpu(), "v": trainer.flat.v.cpu(), "step": trainer.step_count},
-                   os.path.join(output_dir, "optimizer.bin"))
+        for i, m in enumerate(models):
+            sd = {("base_model.model." + n): p.detach().float().cpu().contiguous() for n, p in m.named_parameters() if "lora_" in n}
+            save_file(sd, os.path.join(output_dir, "model.safetensors" if i == 0 else f"model_{i}.safetensors"))
+        if trainer is not None:
+            torch.save({"m": trainer.flat.m.cpu(), "v": trainer.flat.v.cpu(), "step": trainer.step_count},
+                       os.path.join(output_dir, "optimizer.bin"))
+        for i, o in enumerate(self._optimizers):
+            torch.save(o.state_dict(), os.path.join(output_dir, "optimizer.bin" if (i == 0 and trainer is None) else f"optimizer_{i}.bin"))
+        for i, sch in enumerate(self._schedulers):
+            torch.save(sch.state_dict(), os.path.join(output_dir, "scheduler.bin" if i == 0 else f"scheduler_{i}.bin"))
 
     def end_training(self):
         self.wait_for_everyone()
+        if self._log_file is not None:
+            self._log_file.close()
+            self._log_file = None

@@ -47,6 +47,23 @@ class DenoiseEngine:
         self.rowbias = None          # [chains][nbc, temb_total] fp32: the current step's row (gathered on the device)
         self.graph = None
         self._side = None
+        # The captured graph holds raw pointers into the UNet's packed operands (unet.plan()): keep that plan alive for as long
+        # as the graph exists and remember its version, so a later state load / LoRA update (which bumps unet.plan_version) is
+        # noticed instead of replaying the old weights -- or freed memory.
+        self._plan_ref = None
+        self.plan_version = None
+
+    def stale(self):
+        """True when the UNet's packed operands changed after this engine captured its graph."""
+        return self.plan_version is not None and self.plan_version != self.unet.plan_version
+
+    def _check_fresh(self):
+        if self.stale():
+            if self.graph is None:                     # eager launches re-plan by themselves
+                self._plan_ref, self.plan_version = self.unet.plan(), self.unet.plan_version
+                return
+            raise ops._lib.AldmError("DenoiseEngine: the UNet's weights changed after this graph was captured "
+                                     "(load_state_dict / LoRA update); call capture() again or build a new engine")
 
     def set_condition(self, prompt_embeds, negative_prompt_embeds=None):
         """[B, D] L2-normalised prompt embeddings (CLAP text_embeds); CFG order is [negative | positive]."""
@@ -110,6 +127,8 @@ class DenoiseEngine:
 
     def capture(self):
         """Warm up (loads code objects, sizes the split-K workspace) and capture one step."""
+        self.graph = None
+        self._plan_ref, self.plan_version = self.unet.plan(), self.unet.plan_version
         saved = (self.x.clone(), [t.clone() for t in self.x_in], self.step_idx.clone(), self.t_buf.clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -127,6 +146,7 @@ class DenoiseEngine:
         torch.cuda.synchronize()
 
     def step(self):
+        self._check_fresh()
         if self.graph is not None:
             self.graph.replay()
         else:

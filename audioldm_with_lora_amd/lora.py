@@ -72,6 +72,15 @@ class PeftModel(nn.Module):
     def forward(self, *a, **k):
         return self.base_model.model(*a, **k)
 
+    def load_state_dict(self, *a, **k):
+        """[REF script/inference/generate_audio.py:32-33] loads the adapter through the wrapper: the wrapped UNet's packed
+        operands (and any captured denoise graph) must follow."""
+        out = super().load_state_dict(*a, **k)
+        inner = self.base_model.model
+        if hasattr(inner, "invalidate_packed"):
+            inner.invalidate_packed()
+        return out
+
     def __getattr__(self, name):
         try:
             return super().__getattr__(name)

@@ -206,15 +206,23 @@ def halo_tiles(OW, eligible):
 # At run time the table is only looked up; GEMMs it does not hold fall back to the heuristics.
 TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 TUNED = {}
+TUNED_LEGACY_KEYS = False
 TUNER = None
 if os.path.exists(TUNED_PATH) and os.environ.get("ALDM_NO_TUNED") != "1":
     with open(TUNED_PATH) as _f:
         TUNED = {k: tuple(v) for k, v in json.load(_f)["igemm"].items()}
+TUNED_LEGACY_KEYS = any(" k3x3 " in k and " ow" not in k for k in TUNED)
 
 
-def tune_key(M, N, c1, c2, kh, kw, stride, up, dilate, rp, vt, geglu, ln, fast):
-    return (f"M{M} N{N} C{c1}+{c2} k{kh}x{kw} s{stride[0]} up{int(up)} d{dilate} r{rp} vt{int(vt)} g{int(bool(geglu))} "
-            f"ln{int(ln)} f{int(fast)}")
+def tune_key(M, N, c1, c2, kh, kw, stride, up, dilate, rp, vt, geglu, ln, fast, ow=None, pad=None, dil=None):
+    """Key of one GEMM in the measured table.  The geometry suffix (output width, padding, filter dilation) is part of the key for
+    every filter larger than 1x1: two convolutions with equal M / N / C can differ in OW (UNet level 0 is 16 wide, the VAE
+    decoder's last level 64) and then differ in which tiles are even legal (the halo tiles need BM % OW == 0)."""
+    key = (f"M{M} N{N} C{c1}+{c2} k{kh}x{kw} s{stride[0]} up{int(up)} d{dilate} r{rp} vt{int(vt)} g{int(bool(geglu))} "
+           f"ln{int(ln)} f{int(fast)}")
+    if ow is not None and (kh > 1 or kw > 1):
+        key += f" ow{ow} p{pad[0]}x{pad[1]} dl{dil[0]}x{dil[1]}"
+    return key
 
 
 def heuristic_cfg(M, pw, ktiles, can_split, fast_path, has_vt, splits=None):
@@ -350,6 +358,8 @@ class Deferred:
     __slots__ = ("out", "ws", "eff", "bias", "rowbias", "rowbias_ld", "res", "keep")
 
     def __init__(self, out, ws, eff, bias, rowbias, rowbias_ld, res, keep):
+        global DEFERRED_COUNT
+        DEFERRED_COUNT += 1
         self.out, self.ws, self.eff, self.bias, self.rowbias, self.rowbias_ld, self.res = out, ws, eff, bias, rowbias, rowbias_ld, res
         self.keep = keep                                   # tensors the pointers above refer to
 
@@ -358,6 +368,7 @@ class Deferred:
         return self.out.shape
 
 
+DEFERRED_COUNT = 0                                         # diagnostics / tests: how many split-K launches deferred their reduce
 _PENDING = None                                            # the Deferred whose partial tiles currently own the workspace
 
 
@@ -465,14 +476,20 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if tile == 0 and ring == 0:
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
+        sfx = ("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "")
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
-                       pw.ln_s is not None, fast_path) + ("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "")
+                       pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
+        halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
+                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None
+                          and (up_size is None or up_size == (2 * IH, 2 * IW)))
         cfg = TUNED.get(key)
+        if cfg is None and TUNED_LEGACY_KEYS:           # tables written before the geometry suffix existed
+            cfg = TUNED.get(tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None,
+                                     pw.geglu, pw.ln_s is not None, fast_path) + sfx)
+        if cfg is not None and cfg[0] in HALO_ROWS and cfg[0] not in halo:
+            cfg = None                                  # never trust a table entry into a tile this geometry cannot take
         tuning = TUNER is not None and not torch.cuda.is_current_stream_capturing()
         if tuning:
-            halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
-                              and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None
-                              and (up_size is None or up_size == (2 * IH, 2 * IW)))
             cfg = TUNER.choose(key, a, M, pw, ktiles, can_split and splits is None, splits, fast_path, vt is not None, x.device, halo)
         if cfg is not None:
             tile, ring, splits = cfg

@@ -28,6 +28,8 @@ class AudioPipelineOutput(SimpleNamespace):
 class AudioLDMPipeline:
     def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, vocoder):
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        # the reference hands the pipeline either the bare UNet [REF generate_audio.py:42] or the peft wrapper
+        # (accelerator.unwrap_model(unet) is the PeftModel [REF train:598-599]); both keep `.unet` as given
         self.unet, self.scheduler, self.vocoder = unet, scheduler, vocoder
         self.vae_scale_factor = 2 ** (len(vae.cfg["block_out_channels"]) - 1)
         self.device = torch.device("cpu")
@@ -51,6 +53,11 @@ class AudioLDMPipeline:
             text_encoder = ClapTextModelWithProjection.from_pretrained(os.path.join(path, "text_encoder"))
             tokenizer = RobertaTokenizerFast.from_pretrained(os.path.join(path, "tokenizer"))
         return cls(vae, text_encoder, tokenizer, unet, scheduler, vocoder)
+
+    @property
+    def _unet(self):
+        """the UNet2DConditionModel behind `.unet` (unwraps a lora.PeftModel)"""
+        return getattr(getattr(self.unet, "base_model", None), "model", self.unet)
 
     def to(self, device):
         self.device = torch.device(device)
@@ -84,9 +91,12 @@ class AudioLDMPipeline:
 
     def engine(self, batch, h, w, steps, guidance):
         key = (batch, h, w, steps, float(guidance))
-        if key not in self._engines:
-            self._engines[key] = DenoiseEngine(self.unet, self.scheduler, batch, h, w, steps, guidance, device=self.device)
-        return self._engines[key]
+        eng = self._engines.get(key)
+        if eng is not None and (eng.unet is not self._unet or eng.stale()):
+            eng = None                                  # weights / adapter changed since the capture: never replay the old graph
+        if eng is None:
+            eng = self._engines[key] = DenoiseEngine(self._unet, self.scheduler, batch, h, w, steps, guidance, device=self.device)
+        return eng
 
     def decode_latents_nhwc(self, x_nhwc_f32):
         """steps 6-7: latents [B, h, w, 8] fp32 channels-last -> waveform [B, 160*4h + 32] fp32 (device)."""
@@ -127,7 +137,7 @@ class AudioLDMPipeline:
                 negative_prompt_embeds = negative_prompt_embeds.repeat_interleave(num_waveforms_per_prompt, dim=0)
             batch = prompt_embeds.shape[0]
         h, w = height // self.vae_scale_factor, vc.model_in_dim // self.vae_scale_factor
-        shape = (batch, self.unet.cfg["in_channels"], h, w)
+        shape = (batch, self._unet.cfg["in_channels"], h, w)
         if latents is None:
             gdev = generator.device if generator is not None else torch.device("cpu")
             latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)

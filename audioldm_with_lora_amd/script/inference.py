@@ -31,6 +31,7 @@ def main(argv=None):
     ap.add_argument("--audio-length", type=float, default=10.0)
     ap.add_argument("--guidance-scale", type=float, default=5.0)
     ap.add_argument("--output", default="./generated_audio_LoRA/ex.wav")
+    ap.add_argument("--seed", type=int, default=None, help="seed of the initial-noise generator (the reference seeds nothing, quirk Q5)")
     args = ap.parse_args(argv)
 
     device = "cuda"
@@ -42,8 +43,9 @@ def main(argv=None):
             from safetensors.torch import load_file
             unet_lora.load_state_dict(load_file(args.lora_weights), strict=False)
     pipe = AudioLDMPipeline.from_pretrained(args.model_dir, unet=unet).to(device)
+    generator = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
     audio = pipe(prompt=args.prompt, num_inference_steps=args.steps, audio_length_in_s=args.audio_length,
-                 guidance_scale=args.guidance_scale).audios[0]
+                 guidance_scale=args.guidance_scale, generator=generator).audios[0]
     os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
     from scipy.io import wavfile
     wavfile.write(args.output, 16000, np.asarray(audio, dtype=np.float32))

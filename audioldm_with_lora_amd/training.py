@@ -263,6 +263,8 @@ class FlatLora:
         self.m = torch.zeros(total, dtype=torch.float32, device=device)
         self.v = torch.zeros(total, dtype=torch.float32, device=device)
         self._off = {}
+        self._plist = []
+        self.on_change = None             # set by the owning trainer: called after any optimiser update of the buffer
         off = 0
         for n, p in named:
             k = p.numel()
@@ -270,17 +272,63 @@ class FlatLora:
             p.data = self.params[off:off + k].view(p.shape)
             p.grad = self.grads[off:off + k].view(p.shape)
             p.requires_grad_(True)
+            p._aldm_flat = (self, off)    # optim.AdamW finds the flat buffer through its parameters
             self._off[id(p)] = off
+            self._plist.append((p, off, k))
             off += k
 
     def offset_of(self, p):
         return self._off[id(p)]
 
+    def bind_grads(self):
+        """(Re-)attach every parameter's .grad as a view of the flat gradient buffer (optimizer.zero_grad() sets them to None)."""
+        for p, off, k in self._plist:
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * off:
+                p.grad = self.grads[off:off + k].view(p.shape)
+
+    def intact(self):
+        """False once a parameter no longer aliases the flat buffer (module.to(), a state load that re-created the tensors)."""
+        base = self.params.data_ptr()
+        return all(p.data_ptr() == base + 4 * off for p, off, _ in self._plist)
+
+    def owner_changed(self):
+        if self.on_change is not None:
+            self.on_change()
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """`unet(noisy, t, class_labels=emb)[0]` for a LoRA-wrapped UNet in training mode  [REF script/train/train_audioldm_lora.py:539-546]:
+    forward = the taped HIP launch sequence, backward = the tape run in reverse (dX through the frozen base, dA / dB scattered
+    into the flat gradient buffer).  The LoRA parameters are inputs of the Function only so that autograd schedules it; their
+    gradients are WRITTEN by the kernels into the flat buffer and `p.grad` is bound to views of it -- nothing is returned for
+    them, so autograd makes no copies and `accelerator.backward(loss)` / `optimizer.step()` [REF train:557-565] see one buffer."""
+
+    @staticmethod
+    def forward(ctx, trainer, sample, timestep, class_labels, *lora_params):
+        ctx.trainer = trainer
+        ctx.nparams = len(lora_params)
+        return trainer._taped_forward(sample, timestep, class_labels)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.trainer._taped_backward(grad_out)
+        return (None, None, None, None) + (None,) * ctx.nparams
+
+
+def trainer_of(unet, create=True):
+    """The training engine attached to a UNet (created on first use: flattens the LoRA parameters, builds the fused sites)."""
+    tr = getattr(unet, "_trainer", None)
+    if tr is not None and not tr.flat.intact():
+        tr = None                                            # the parameters were moved / reloaded: rebuild
+    if tr is None and create:
+        tr = LoraTrainer(unet, None, use_graph=False)
+    return tr
+
 
 class LoraTrainer:
     """One process per GPU; `world`/`rank` follow torch.distributed when it is initialised (RCCL over xGMI)."""
 
-    def __init__(self, unet: UNet2DConditionModel, scheduler, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-5, eps=1e-8,
+    def __init__(self, unet: UNet2DConditionModel, scheduler=None, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-5, eps=1e-8,
                  max_train_steps=97000, lr_end=1e-7, power=1.0, device="cuda", use_graph=True):
         self.unet, self.scheduler = unet, scheduler
         self.dev = torch.device(device)
@@ -289,10 +337,15 @@ class LoraTrainer:
         self.step_count = 0
         self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
+        if not any("lora_" in n for n, _ in unet.named_parameters()):
+            raise ops._lib.AldmError("LoraTrainer: the UNet carries no LoRA parameters (call get_peft_model first)")
         self.flat = FlatLora(unet, self.dev)
+        self.flat.on_change = unet.invalidate_packed         # an optimiser update makes the UNet's inference plan stale
         self.use_graph, self.graph, self._static, self._eager_steps = use_graph, None, None, 0
-        self.ac_dev = scheduler.alphas_cumprod.to(self.dev, torch.float32)
+        self.ac_dev = scheduler.alphas_cumprod.to(self.dev, torch.float32) if scheduler is not None else None
+        self._tape = None
         self._build_sites()
+        unet.__dict__["_trainer"] = self                     # plain attribute (not a submodule): unet(...) in training mode finds it
         self.tnb = ops.TnBatch(4 * len(self.sites) + 8, self.dev)       # <= 2 sites per attention, 2 products per site
         dp.broadcast_(self.flat.params, src=0)                  # DDP's initial parameter broadcast (C3), LoRA buffer only
 
@@ -459,6 +512,42 @@ class LoraTrainer:
         h = t_groupnorm(tape, h, P.gn_out[0], P.gn_out[1], groups, eps, ACT_SILU)
         return t_conv(tape, h, P.conv_out, pad=(1, 1), out_f32=True)
 
+    # ---- autograd-shaped boundary (the reference's own loop body drives these through unet(...) / loss.backward()) ----
+    def _taped_forward(self, sample, timestep, class_labels):
+        f = self.flat
+        b = sample.shape[0]
+        self.repack()
+        f.grads.zero_()
+        t = timestep.to(device=self.dev, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1 and b > 1:
+            t = t.expand(b)
+        x_in = ops.nchw_to_nhwc(sample.detach().to(self.dev, torch.float32).contiguous())
+        cls = ops.f32_to_bf16(class_labels.detach().to(self.dev, torch.float32).contiguous())
+        tape = Tape(self.tnb)
+        pred = self.forward(tape, x_in, t.contiguous(), cls)
+        self._tape = (tape, pred)
+        return ops.nhwc_to_nchw_f32(pred.t).to(sample.dtype)
+
+    def _taped_backward(self, grad_out):
+        if self._tape is None:
+            raise ops._lib.AldmError("backward called twice on one UNet forward (the launch tape is consumed by the first call)")
+        tape, pred = self._tape
+        self._tape = None
+        pred.g = ops.nchw_to_nhwc(grad_out.detach().to(self.dev, torch.float32).contiguous())     # bf16 activation-gradient
+        tape.backward()
+        self.tnb.launch()
+        self.flat.bind_grads()
+
+    def autograd_forward(self, sample, timestep, class_labels):
+        params = [p for p, _, _ in self.flat._plist]
+        return _UNetTrainFn.apply(self, sample, timestep, class_labels, *params)
+
+    def allreduce_grads_(self):
+        """DDP's gradient all-reduce (C1) for the autograd-shaped path: ONE collective over the flat buffer, then 1 / world."""
+        if self.dist and self.world > 1:
+            self.dist.all_reduce(self.flat.grads)
+            self.flat.grads.mul_(1.0 / self.world)
+
     # ---- schedule / step ----
     def lr(self, step):
         """diffusers get_scheduler("polynomial") with 0 warm-up [REF train:438-443]."""
@@ -471,6 +560,8 @@ class LoraTrainer:
         f = self.flat
         self.repack()
         f.grads.zero_()
+        if self.ac_dev is None:
+            raise ops._lib.AldmError("LoraTrainer.step needs the noise scheduler (pass scheduler= to the constructor)")
         ac = self.ac_dev[timesteps]
         coef = torch.stack([ac ** 0.5, (1 - ac) ** 0.5], dim=1).contiguous()
         noisy = ops.add_noise(latents, noise, coef)
@@ -524,4 +615,8 @@ class LoraTrainer:
         self.step_count += 1
         ops.adamw_flat(f.params, f.grads, f.m, f.v, self.lr(self.step_count - 1), self.betas[0], self.betas[1], self.eps,
                        self.wd, self.step_count, grad_scale=1.0 / self.world)
+        # the adapter changed: the UNet's INFERENCE plan (bf16 A / B packed at plan time) is stale.  The trainer keeps its own
+        # reference (self.P: frozen operands only; its LoRA operands are refreshed by repack()), so this only makes the next
+        # pipe(unet=unet) / unet(...) call re-pack -- the in-training validation of [REF train:597-603] then sees the trained LoRA.
+        self.unet.invalidate_packed()
         return loss / self.world

@@ -314,6 +314,7 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, padding=1)
         self.num_upsamplers = len(boc) - 1
         self._plan = None
+        self._plan_version = 0        # bumped whenever the packed operands may be stale (see invalidate_packed)
 
     # ---- drop-in plumbing ----
     @classmethod
@@ -336,15 +337,29 @@ class UNet2DConditionModel(nn.Module):
         m.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")), strict=True)
         return m
 
+    def _has_trainable_lora(self):
+        return any(isinstance(m, LoraLinear) and m.lora_A["default"].weight.requires_grad for m in self.modules())
+
     def invalidate_packed(self):
+        """Forget the packed bf16 operands: call after ANY change of parameter values the module hooks cannot see (in-place
+        edits of `.data`).  State loads, `.to()`, peft injection, PeftModel.load_state_dict and LoraTrainer steps call it
+        themselves.  The version counter lets holders of captured graphs (engine.DenoiseEngine) notice that the plan they
+        captured pointers into is no longer the live one."""
         self._plan = None
+        self._plan_version += 1
+
+    @property
+    def plan_version(self):
+        return self._plan_version
 
     def _apply(self, fn, *a, **k):
-        self._plan = None
+        # (a training engine attached to this UNet survives a no-op .to(): training.trainer_of() checks that the LoRA
+        # parameters still alias its flat buffer and rebuilds only when they were really moved)
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._plan = None
+        self.invalidate_packed()
         return super().load_state_dict(*a, **k)
 
     # ---- packing ----
@@ -392,6 +407,7 @@ class UNet2DConditionModel(nn.Module):
         P.temb_total = off
         P.gn_out = (_f32(self.conv_norm_out.weight), _f32(self.conv_norm_out.bias))
         P.conv_out = ops.pack_conv(self.conv_out.weight, self.conv_out.bias)
+        P.version = self._plan_version
         self._plan = P
         return P
 
@@ -497,6 +513,12 @@ class UNet2DConditionModel(nn.Module):
         t = timestep.to(device=sample.device, dtype=torch.float32).reshape(-1)
         if t.numel() not in (1, b):
             raise ValueError("timestep must be a scalar or have one entry per sample")
+        if self.training and torch.is_grad_enabled() and self._has_trainable_lora():
+            # the reference's training call [REF train:479,539-546]: return a tensor autograd can differentiate -- forward and
+            # backward both run on the HIP launch tape (training._UNetTrainFn)
+            from .training import trainer_of
+            out = trainer_of(self).autograd_forward(sample, t, class_labels)
+            return SimpleNamespace(sample=out) if return_dict else (out,)
         x = ops.nchw_to_nhwc(sample.float())
         cls_bf16 = ops.f32_to_bf16(class_labels.to(device=sample.device, dtype=torch.float32).contiguous())
         eps = self.forward_nhwc(x, t.contiguous(), cls_bf16)
