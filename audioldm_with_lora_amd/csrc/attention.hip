@@ -5,10 +5,20 @@
 // V^T fragment reads reproduce with two 8-byte LDS reads).  K / V^T tiles of 64 keys are shared by the
 // workgroup's waves through padded (bank-conflict-free) LDS images, register-prefetched one tile ahead.
 //
+// The loop is VALU-bound (softmax), not MFMA-bound, at d = 32 .. 80, so the per-key VALU work is cut to its essentials:
+//   * the running maximum enters as the INITIAL ACCUMULATOR of the S^T MFMAs (S' = K Q^T - m), so p = exp2(S') needs no
+//     per-element subtraction; the maximum is only raised when a tile exceeds it by more than RESCALE_THR (deferred rescale,
+//     wave-uniform branch) -- P is then bounded by 2^THR instead of 1, which fp32 accumulation and bf16 P tolerate
+//   * the softmax scale is folded into the Q projection weights by the caller (PRESCALED) -- no multiply per score
+//   * the row sum l = sum_k p rides in the P V MFMAs: V^T carries one extra row of ones (row DP of the LDS image), so l
+//     accumulates in the O^T tile like any other output row, from the SAME bf16-rounded P that multiplies V
+//   * running max over a tile with v_max3_f32 (16 instructions for 32 scores)
+//
 // Serves F.scaled_dot_product_attention inside diffusers AttnProcessor2_0 for the 32 Attention modules of
 // UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546].  Head dims 32/48/80
 // (8 heads at C = 256/384/640), sequence lengths 1000/252/64 (10 s) and 1024/256/64 (training).
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -16,10 +26,21 @@ namespace {
 constexpr int KV = 64;           // keys per tile
 constexpr int VS = 136;          // V^T LDS row stride in bytes (64 keys * 2 B + 8 B pad): conflict-free ds_read_b64
 
+constexpr float RESCALE_THR = 5.0f;   // log2 units: the running max is raised only when a tile's max exceeds it by more than this
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 template <int DP>
 struct AttnCfg {
   static constexpr int DK = DP / 16;                       // QK^T k-steps
-  static constexpr int DT = (DP + 31) / 32;                // 32-row d-tiles of O^T
+  static constexpr int DT = DP / 32 + 1;                   // 32-row d-tiles of O^T, INCLUDING the row of ones at row DP
+  static constexpr int ONES_T = DP / 32;                   // tile / accumulator register that holds l = sum p (lanes hh = 0)
+  static constexpr int ONES_I = 4 * ((DP % 32) >> 3);
+  static_assert(DP % 16 == 0, "row DP must land on hh = 0, register 4 * (row / 8)");
   static constexpr int KS = DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);  // K LDS row stride (odd number of 16-B slots)
   static constexpr int KBYTES = KV * KS;
   static constexpr int VBYTES = DT * 32 * VS;
@@ -30,7 +51,7 @@ struct AttnCfg {
 // works on tile g, and the groups' (max, sum, O^T) are merged through LDS at the end.  At N = 1000 / 252 with 8 x 8 heads a
 // query block per wave gives only 2 / 0.5 waves per SIMD; the split doubles the independent instruction streams that hide
 // the MFMA -> softmax -> MFMA dependency chain.
-template <int DP, int NW, int SP>
+template <int DP, int NW, int SP, bool PRESCALED>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restrict__ q, int ldq,
                                                             const bf16* __restrict__ k, int ldk,
                                                             const bf16* __restrict__ vt, int vt_ld, long long vt_bs,
@@ -86,12 +107,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     return;
   }
 
-  // zero the d-padding rows of both V^T buffers once (rows D .. DT*32-1 stay zero for the whole kernel)
+  // rows D .. DT*32-1 of both V^T buffers are written once and stay for the whole kernel: zero (head-dim padding), except
+  // row DP = ones (bf16 1.0 pairs): the P V MFMAs then also accumulate l = sum_k p in O^T row DP
   {
-    const int npad = DT * 32 - D;                      // rows to clear per buffer (0 when D is a multiple of 32)
+    const int npad = DT * 32 - D;
     for (int i = tid; i < 2 * SP * npad * (VS / 8); i += T) {
       const int buf = i / (npad * (VS / 8)), rem = i - buf * npad * (VS / 8);
-      reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + D * VS)[rem] = make_uint2(0u, 0u);
+      const unsigned fill = (D + rem / (VS / 8) == DP) ? 0x3F803F80u : 0u;
+      reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + D * VS)[rem] = make_uint2(fill, fill);
     }
   }
 
@@ -166,7 +189,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = 0.f;                            // running maximum of the SCALED scores (log2 domain); set by the first tile
 
   const int ntiles = (Nk + KV - 1) / KV;
   const int niter = (ntiles + SP - 1) / SP;
@@ -175,20 +198,27 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   prefetch(0, Set0{});
   if (niter > 1) prefetch(SP * KV, Set1{});
   stage(0, Set0{});
+  // Drain every global load issued so far (Q fragments, both prefetch sets) HERE, with the builtin the compiler's wait-count pass
+  // models: otherwise the first use of the Q fragments inside the loop gets an `s_waitcnt vmcnt(0)` that, from the second
+  // iteration on, waits for the K / V^T prefetch issued a few instructions earlier -- a full L2 round trip exposed per tile, in
+  // every wave at once (the ISA showed exactly that).  vmcnt = 0, expcnt / lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
   auto iteration = [&](int it, auto curc) {     // curc: the register set that is free (its tile-group was staged last iteration)
     constexpr int CUR = decltype(curc)::value;
     const int buf = (it & 1) * SP + grp, kv0 = (it * SP + grp) * KV;
+    const bool first = it == 0;
     if (it + 2 < niter) prefetch((it + 2) * SP * KV, curc);
     if (SP == 1 || kv0 < Nk) {                 // (wave-uniform) a group past the last tile of an odd count sits this one out
 
-    // ---- S^T = K Q^T for two 32-key sub-tiles ----
+    // ---- S' = K Q^T (- m_run as the initial accumulator when the scores come out of the MFMA already scaled) ----
     f32x16 s[2];
+    const float acc0 = PRESCALED ? -m_run : 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+      for (int i = 0; i < 16; ++i) s[sub][i] = acc0;
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + buf * Cfg::KBYTES + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
@@ -204,34 +234,46 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
           if (kvr >= Nk) s[sub][i] = -INFINITY;
         }
     }
-    // ---- online softmax (lane-local: this lane's query column) ----
-    float mx = s[0][0];
+    // ---- online softmax (lane-local: this lane's query column), deferred rescale ----
+    float mx0 = max3f(s[0][0], s[0][1], s[0][2]), mx1 = max3f(s[1][0], s[1][1], s[1][2]);   // two independent chains
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+    for (int i = 3; i < 15; i += 2) {
+      mx0 = max3f(mx0, s[0][i], s[0][i + 1]);
+      mx1 = max3f(mx1, s[1][i], s[1][i + 1]);
+    }
+    float mx = max3f(mx0, mx1, fmaxf(s[0][15], s[1][15]));
+    {   // the other 32 keys of this query column sit in lane ^ 32: v_permlane32_swap (VALU) instead of an LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    // excess of this tile's maximum over the running one, in the scaled (log2) domain
+    const float ex = PRESCALED ? mx : fmaf(mx, c, -m_run);
+    if (first || !__all(ex <= RESCALE_THR)) {
+      const float delta = first ? ex : fmaxf(ex, 0.f);                  // the maximum never decreases after the first tile
+      m_run += delta;
+      if (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[t][i] *= alpha;                // includes l (row DP)
+      }
+      if (PRESCALED) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[sub][i] -= delta;
+      }
+    }
     bf16x8 pf[4];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][i], c, -m_new));
-        psum += pv;
-        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)pv;
+        const float e = PRESCALED ? s[sub][i] : fmaf(s[sub][i], c, -m_run);
+        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)__builtin_amdgcn_exp2f(e);
       }
-    l_run = l_run * alpha + psum;
-    if (!__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
-    }
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V^T P^T (row DP of V^T is ones: l accumulates alongside) ----
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -254,43 +296,44 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   if constexpr (SP > 1) {
     // ---- merge the key groups: groups 1.. leave (m, l, O^T) in LDS (the staging buffers are dead after the last barrier),
     // group 0 folds them in.  Layout [value][lane] per wave: conflict-free 4-byte accesses. ----
-    constexpr int WVALS = DT * 16 + 2;
+    constexpr int WVALS = DT * 16 + 1;
     float* xch = reinterpret_cast<float*>(smem);
+    const bool idle = grp * KV >= Nk;                            // (wave-uniform) this group never saw a tile: O^T = 0, l = 0
     if (grp > 0) {
       float* mine = xch + ((grp - 1) * QW + (wave - grp * QW)) * WVALS * 64;
-      mine[lane] = m_run;
-      mine[64 + lane] = l_run;
+      mine[lane] = idle ? -INFINITY : m_run;
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mine[(2 + t * 16 + i) * 64 + lane] = o[t][i];
+        for (int i = 0; i < 16; ++i) mine[(1 + t * 16 + i) * 64 + lane] = o[t][i];
     }
     __syncthreads();
     if (grp > 0) return;
 #pragma unroll
     for (int g = 1; g < SP; ++g) {
       const float* peer = xch + ((g - 1) * QW + wave) * WVALS * 64;
-      const float m1 = peer[lane], l1 = peer[64 + lane];
+      const float m1 = peer[lane];
       const float m_new = fmaxf(m_run, m1);                      // m_run is finite: group 0 always owns tile 0
       const float a0 = __builtin_amdgcn_exp2f(m_run - m_new), a1 = __builtin_amdgcn_exp2f(m1 - m_new);   // a1 = 0 for an idle group
       m_run = m_new;
-      l_run = l_run * a0 + l1 * a1;
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * a0 + peer[(2 + t * 16 + i) * 64 + lane] * a1;
+        for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * a0 + peer[(1 + t * 16 + i) * 64 + lane] * a1;   // l (row DP) merges like any row
     }
   }
 
   // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  // l sits in O^T row DP: register ONES_I of tile ONES_T on the hh = 0 lanes (the hh = 1 lanes hold row DP + 4 there: zero padding)
+  const float l_half = o[Cfg::ONES_T][Cfg::ONES_I];
+  const float l_tot = l_half + __shfl_xor(l_half, 32, 64);
   const float inv = 1.0f / l_tot;
   if (lse && hh == 0 && q0 + r < N)   // log2-domain log-sum-exp of the scaled scores: p = exp2(s*c - lse)
     lse[((long long)b * gridDim.y + head) * N + q0 + r] = m_run + __log2f(l_tot);
   if (q0 + r < N) {
     bf16* orow = out + ((long long)b * N + q0 + r) * out_ld + head * D;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t = 0; t < (DP + 31) / 32; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = t * 32 + 8 * g + 4 * hh;
@@ -302,11 +345,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   }
 }
 
-template <int DP, int NW, int SP = 1>
+template <int DP, int NW, int SP, bool PS>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
                 int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   using Cfg = AttnCfg<DP>;
-  auto kern = attention_kernel<DP, NW, SP>;
+  auto kern = attention_kernel<DP, NW, SP, PS>;
   constexpr int LDS = 2 * SP * Cfg::TILE;
   static_assert(SP == 1 || (SP - 1) * (NW / SP) * (Cfg::DT * 16 + 2) * 256 <= LDS, "merge buffer must fit the staging area");
   static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
@@ -318,7 +361,7 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, 
   return aldm_launch_status("attention");
 }
 
-template <int DP>
+template <int DP, bool PS>
 int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
                   int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   // measured in a replayed graph: N = 1000 (d 32) 4 waves 24 us vs 2 waves 31; N = 252 (d 48) 4 waves 8.9 us vs 2 waves 9.4;
@@ -328,14 +371,20 @@ int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt
   // N = 1000 with 4 heads 16.6 -> 14.6 us; at N = 1000 x 64 (batch, head) pairs the kernel is VALU-throughput-bound (softmax)
   // and the split only adds the merge: 22.9 -> 23.4 us, so the full-size case keeps one wave per query block
 #define ALDM_ATTN_ARGS q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st
+  static const int force = getenv("ALDM_ATTN_CFG") ? atoi(getenv("ALDM_ATTN_CFG")) : 0;   // tuning aid: 10 * waves + key split
+  if (force == 81) return launch_attn<DP, 8, 1, PS>(ALDM_ATTN_ARGS);
+  if (force == 82) return launch_attn<DP, 8, 2, PS>(ALDM_ATTN_ARGS);
+  if (force == 41) return launch_attn<DP, 4, 1, PS>(ALDM_ATTN_ARGS);
+  if (force == 42) return launch_attn<DP, 4, 2, PS>(ALDM_ATTN_ARGS);
+  if (force == 21) return launch_attn<DP, 2, 1, PS>(ALDM_ATTN_ARGS);
   if (N >= 768) {
-    if ((long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8>(ALDM_ATTN_ARGS);
-    return launch_attn<DP, 8, 2>(ALDM_ATTN_ARGS);
+    if ((long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8, 1, PS>(ALDM_ATTN_ARGS);
+    return launch_attn<DP, 8, 2, PS>(ALDM_ATTN_ARGS);
   }
-  if (N >= 192) return launch_attn<DP, 4, 2>(ALDM_ATTN_ARGS);
+  if (N >= 192) return launch_attn<DP, 4, 2, PS>(ALDM_ATTN_ARGS);
+  if (N >= 64) return launch_attn<DP, 4, 1, PS>(ALDM_ATTN_ARGS);   // N = 64 x 64 (batch, head) pairs: 4 waves 5.2 us vs 2 waves 5.7 us
+  return launch_attn<DP, 1, 1, PS>(ALDM_ATTN_ARGS);
 #undef ALDM_ATTN_ARGS
-  if (N >= 64) return launch_attn<DP, 2>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
-  return launch_attn<DP, 1>(q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st);
 }
 
 // ---- row softmax (VAE mid-block attention runs QK^T / PV through the GEMM kernel) ----
@@ -362,6 +411,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
+template <bool PS>
 static int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                           long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                           float* lse, const int* kv_len, void* stream) {
@@ -370,7 +420,7 @@ static int attention_impl(const void* q, int ldq, const void* k, int ldk, const 
   ALDM_CHECK_ARG(d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0, "attention: d/ld must be multiples of 8");
   ALDM_CHECK_ARG(vt_ld >= ((N + 7) / 8) * 8, "attention: vt_ld %d too small for N %d", vt_ld, N);
   hipStream_t st = (hipStream_t)stream;
-#define ALDM_ATTN(DPV) return launch_attn_d<DPV>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, kv_len, st)
+#define ALDM_ATTN(DPV) return launch_attn_d<DPV, PS>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, kv_len, st)
   if (d <= 16) ALDM_ATTN(16);
   if (d <= 32) ALDM_ATTN(32);
   if (d <= 48) ALDM_ATTN(48);
@@ -384,21 +434,29 @@ static int attention_impl(const void* q, int ldq, const void* k, int ldk, const 
 extern "C" int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                               long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                               void* stream) {
-  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, nullptr, stream);
+  return attention_impl<false>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, nullptr, stream);
+}
+
+// Q already carries scale * log2(e) (the caller folded it into the Q projection weights): the scores leave the MFMA in their
+// final log2 domain and the running maximum enters as the MFMA's initial accumulator -- no per-score multiply or subtract.
+extern "C" int aldm_attention_prescaled(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                                        long long vt_batch_stride, int B, int N, int H, int d, void* out, int out_ld,
+                                        void* stream) {
+  return attention_impl<true>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, 1.0f, out, out_ld, nullptr, nullptr, stream);
 }
 
 extern "C" int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                                   long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                                   float* lse, void* stream) {
   ALDM_CHECK_ARG(lse, "attention_lse: null lse");
-  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, nullptr, stream);
+  return attention_impl<false>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, nullptr, stream);
 }
 
 extern "C" int aldm_attention_varlen(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                                      long long vt_batch_stride, int B, int N, int H, int d, float scale,
                                      const int* kv_len, void* out, int out_ld, void* stream) {
   ALDM_CHECK_ARG(kv_len, "attention_varlen: null kv_len");
-  return attention_impl(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, kv_len, stream);
+  return attention_impl<false>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, kv_len, stream);
 }
 
 extern "C" int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out,

@@ -322,9 +322,11 @@ def save_tuned(path=TUNED_PATH):
 
 TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128"}
 
-# Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event).
-# Events are recorded on the stream the kernel is launched on.
+# Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event, site) per C-ABI call.
+# Events are recorded on the stream the kernel is launched on.  SITE tags the launches of one fused-LoRA attention module
+# (unet.run_attention) so that bench.py can price the module as a whole.
 PROFILE = None
+SITE = None
 
 
 def _launch(label, flops, nbytes, fn):
@@ -334,7 +336,7 @@ def _launch(label, flops, nbytes, fn):
     s.record()
     rc = fn()
     e.record()
-    PROFILE.append((label, flops, nbytes, s, e))
+    PROFILE.append((label, flops, nbytes, s, e, SITE))
     return rc
 
 
@@ -594,9 +596,12 @@ def layernorm(x2d, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False):
+LOG2E = 1.4426950408889634
+
+
+def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False, prescaled=False):
     """qk [B*N, 2C] (Q | K), vt [B, C, Npad]; returns [B*N, C].  kv_len: optional int32 [B] valid-key counts
-    (right-padded batches)."""
+    (right-padded batches).  prescaled: Q already carries d^-0.5 * log2(e) (folded into the to_q weights at pack time)."""
     _require_gpu(qk)
     Cc = H * d
     if out is None:
@@ -612,8 +617,13 @@ def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False):
         return out
     if fp8:                                                   # config 5: e4m3 Q / K / V / P operands
         check(_launch(f"attention_fp8_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention_fp8(
-            q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
-            _p(out), Cc, _stream())), "aldm_attention_fp8")
+            q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d,
+            (1.0 / LOG2E) if prescaled else 1.0 / math.sqrt(d), _p(out), Cc, _stream())), "aldm_attention_fp8")
+        return out
+    if prescaled:
+        check(_launch(f"attention_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention_prescaled(
+            q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, _p(out), Cc, _stream())),
+            "aldm_attention_prescaled")
         return out
     check(_launch(f"attention_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention(
         q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
@@ -679,8 +689,9 @@ def f32_to_bf16(x, mul=1.0, out=None):
 def cfg_ddim_step(eps, x, cfg, guidance, coef, step_idx, x_in):
     B = x.shape[0]
     n = x.numel() // B
-    check(_lib.load().aldm_cfg_ddim_step(_p(eps), _p(x), B, n, int(cfg), guidance, _p(coef), _p(step_idx), _p(x_in),
-                                         _stream()), "aldm_cfg_ddim_step")
+    check(_launch("cfg_ddim_step", 6.0 * x.numel(), (4.0 * (2 if cfg else 1) + 8.0 + 2.0 * (2 if cfg else 1)) * x.numel(),
+                  lambda: _lib.load().aldm_cfg_ddim_step(_p(eps), _p(x), B, n, int(cfg), guidance, _p(coef), _p(step_idx), _p(x_in),
+                                                          _stream())), "aldm_cfg_ddim_step")
 
 
 def add_noise(x, noise, coef):
@@ -700,12 +711,13 @@ def gather_row(table, idx, out):
     """out[...] = table[idx[0]] (device-side index); table [n, ...] fp32 contiguous, out one row."""
     row = table[0].numel()
     assert table.dtype == torch.float32 and out.dtype == torch.float32 and out.numel() == row and idx.dtype == torch.int32
-    check(_lib.load().aldm_gather_row(_p(table), _p(idx), row, _p(out), _stream()), "aldm_gather_row")
+    check(_launch("gather_row", 0.0, 8.0 * row, lambda: _lib.load().aldm_gather_row(_p(table), _p(idx), row, _p(out), _stream())),
+          "aldm_gather_row")
 
 
 def advance_step(step_idx, timesteps_f32, t_out):
-    check(_lib.load().aldm_advance_step(_p(step_idx), _p(timesteps_f32), timesteps_f32.numel(), _p(t_out), _stream()),
-          "aldm_advance_step")
+    check(_launch("advance_step", 0.0, 16.0, lambda: _lib.load().aldm_advance_step(_p(step_idx), _p(timesteps_f32), timesteps_f32.numel(),
+                                                                                    _p(t_out), _stream())), "aldm_advance_step")
 
 
 def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):

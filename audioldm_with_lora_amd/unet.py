@@ -183,11 +183,19 @@ def pack_attention(a: Attention, ln=None):
     wv, bv, lv = _lin(a.to_v)
     wo, bo, lo = _lin(a.to_out[0])
     c = wq.shape[0]
+    # the softmax scale d^-0.5 (and log2 e: the kernel exponentiates with v_exp_f32 = 2^x) rides in the Q projection: W_q, its
+    # bias and the LoRA-B rows of to_q are multiplied once, here, BEFORE their bf16 rounding (the rounding error of w * s is the
+    # rounding error of w), so the attention kernel never multiplies a score (ops.attention prescaled=True)
+    qs = ops.LOG2E / math.sqrt(a.dim_head)
+    wq = wq.detach().float() * qs
+    bq = None if bq is None else bq.detach().float() * qs
+    lq = None if lq is None else (lq[0], lq[1], lq[2] * qs)
     bias = None
     if bq is not None:
-        bias = torch.cat([bq, bk, bv])
+        bias = torch.cat([bq, bk.detach().float(), bv.detach().float()])
     fold = ln is not None and c % 64 == 0 and c >= LN_FOLD_MIN_C
-    qkv = ops.pack_linear_ln(torch.cat([wq, wk, wv]), bias, ln[0], ln[1]) if fold else ops.pack_linear(torch.cat([wq, wk, wv]), bias)
+    wqkv = torch.cat([wq, wk.detach().float(), wv.detach().float()])
+    qkv = ops.pack_linear_ln(wqkv, bias, ln[0], ln[1]) if fold else ops.pack_linear(wqkv, bias)
     ops.attach_lora(qkv, [None if l is None else (i * c, c, l[0], l[1], l[2]) for i, l in enumerate((lq, lk, lv))])
     out = ops.pack_linear(wo, bo)
     ops.attach_lora(out, [None if lo is None else (0, wo.shape[0], lo[0], lo[1], lo[2])])
@@ -251,9 +259,12 @@ def run_attention(P, hn, h_res, B, N, fp8=False):
     C = P.c
     npad = (N + 7) // 8 * 8
     vt = torch.empty(B, C, npad, dtype=torch.bfloat16, device=hn.device)
+    ops.SITE = f"attn C{C} N{N}"                      # bench.py prices these three launches as ONE fused-LoRA attention module (K1)
     qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad)
-    a = ops.attention(qk.view(B * N, 2 * C), vt, B, N, P.heads, P.d, fp8=fp8)
-    return ops.linear(a, P.out, res=h_res)
+    a = ops.attention(qk.view(B * N, 2 * C), vt, B, N, P.heads, P.d, fp8=fp8, prescaled=True)
+    y = ops.linear(a, P.out, res=h_res)
+    ops.SITE = None
+    return y
 
 
 def transformer_gn(P):

@@ -11,6 +11,12 @@ no collective in the loop -- SURVEY.md 8e), `value` = total steps / max-over-ran
     python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Per-kernel durations come from two sources, both printed:
+  * `trace`  -- the device-side begin/end timestamps of every kernel of the REPLAYED graph (torch.profiler = roctracer in
+                process; the same timestamps `rocprofv3 --kernel-trace` reports -- profiles/r02*_kernel_trace_summary.txt is
+                that command's summary).  `roofline.achieved` and `k1` are computed from these.
+  * `events` -- hipEvent pairs around every launch of one eager step queued behind a sleep kernel (events on the launch stream).
 """
 import argparse
 import json
@@ -51,51 +57,122 @@ def synth_inputs(batch, height, width, seed_off=0):
     return lat, pe, ne
 
 
-def kernel_profile(engine, fine=False):
-    """One eager denoise step with an event pair (on the launch stream) around every launch; returns per-kernel totals."""
+# ---- per-launch measurement -----------------------------------------------------------------------------------------
+def launch_rows(engine):
+    """One eager denoise step with a hipEvent pair (on the launch stream) around every C-ABI call, queued behind a sleep kernel
+    so that the pairs time kernels and not host gaps.  Returns [(label, flops, bytes, event_us, site)] in launch order."""
     from audioldm_with_lora_amd import ops
     ops.PROFILE = []
-    ops.sleep_us(60000)          # queue the whole step behind a 60 ms sleep: event pairs then time kernels, not host gaps
+    ops.sleep_us(60000)
     engine._one_step()
-    empty = []                   # the event pair itself costs time on the stream: calibrate it with empty pairs in the same queue
-    for _ in range(64):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        e.record()
-        empty.append((s, e))
     torch.cuda.synchronize()
-    pair_ms = sorted(s.elapsed_time(e) for s, e in empty)[len(empty) // 2]
     rows, ops.PROFILE = ops.PROFILE, None
+    return [(label, flops, nbytes, s.elapsed_time(e) * 1e3, site) for label, flops, nbytes, s, e, site in rows]
+
+
+def trace_replays(engine, reps=6):
+    """Device timestamps of every kernel of `reps` graph replays (kineto / roctracer).  Returns (kernels per replay as
+    [(name, avg duration us)], avg wall span of one replay in us) or (None, None) when the tracer is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        engine.step()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(reps):
+                engine.step()
+            torch.cuda.synchronize()
+        evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name and "Memset" not in e.name]
+        evs.sort(key=lambda e: e.time_range.start)
+        if not evs or len(evs) % reps:
+            return None, None
+        n = len(evs) // reps
+        per = []
+        for i in range(n):
+            names = {evs[r * n + i].name for r in range(reps)}
+            if len(names) != 1:
+                return None, None
+            per.append((evs[i].name, sum(evs[r * n + i].time_range.elapsed_us() for r in range(reps)) / reps))
+        span = sum(evs[r * n + n - 1].time_range.end - evs[r * n].time_range.start for r in range(reps)) / reps
+        return per, span
+    except Exception as ex:                                  # measurement aid only: never let it take the bench line down
+        print(f"[bench] kernel trace unavailable: {type(ex).__name__}: {ex}", file=sys.stderr)
+        return None, None
+
+
+def join_trace(rows, kernels):
+    """Attach the traced kernel durations to the launch rows (same launch order; a split-K igemm call is two kernels)."""
+    out, k = [], 0
+    for label, flops, nbytes, ev_us, site in rows:
+        if k >= len(kernels):
+            return None
+        us, names = kernels[k][1], [kernels[k][0]]
+        k += 1
+        if k < len(kernels) and "igemm_reduce_kernel" in kernels[k][0] and label.startswith("igemm"):
+            us += kernels[k][1]
+            names.append(kernels[k][0])
+            k += 1
+        out.append((label, flops, nbytes, ev_us, site, us, names))
+    return out if k == len(kernels) else None
+
+
+def aggregate(rows, fine=False):
     agg = {}
-    for label, flops, nbytes, s, e in rows:
-        if not fine:
-            label = label.split("|")[0]
-        a = agg.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        a["ms"] += max(s.elapsed_time(e) - pair_ms, 1e-4)
+    for label, flops, nbytes, ev_us, site, us, names in rows:
+        key = label if fine else label.split("|")[0]
+        a = agg.setdefault(key, dict(us=0.0, ev_us=0.0, flops=0.0, bytes=0.0, launches=0, kernel=names[0]))
+        a["us"] += us
+        a["ev_us"] += ev_us
         a["flops"] += flops
         a["bytes"] += nbytes
         a["launches"] += 1
     return agg
 
 
-def traffic_from_profile(label):
-    """HBM bytes per launch of the dominant kernel family from the committed PMC summary (tools/pmc_traffic.py over two
-    rocprofv3 --pmc passes of this same command; MI355X_MICROARCH.md correction applied).  None when no summary exists."""
+def k1_sites(rows, ubatch, rank_lora):
+    """The fused-LoRA attention module: QKV GEMM + LoRA -> flash attention -> out-proj + LoRA + residual,
+    priced per site with the survey's algorithmic work  b(8NC^2 + 4N^2C + 16NCr) flops,  2bNCs + 4C^2 s + 8Crs bytes (s = 2)."""
+    sites = {}
+    for label, flops, nbytes, ev_us, site, us, names in rows:
+        if not site:
+            continue
+        s = sites.setdefault(site, dict(modules=0, us=0.0, ev_us=0.0, parts={}))
+        part = "attention" if label.startswith("attention") else ("qkv_lora" if "_vt" in label else "out_proj_lora")
+        s["parts"][part] = s["parts"].get(part, 0.0) + us
+        s["us"] += us
+        s["ev_us"] += ev_us
+        s["modules"] += 1 if part == "attention" else 0
+    out = []
+    for site, s in sorted(sites.items()):
+        C, N = int(site.split()[1][1:]), int(site.split()[2][1:])
+        m = s["modules"]
+        flops = ubatch * (8.0 * N * C * C + 4.0 * N * N * C + 16.0 * N * C * rank_lora)
+        nbytes = 2.0 * ubatch * N * C * 2 + 4.0 * C * C * 2 + 8.0 * C * rank_lora * 2
+        t = s["us"] / m * 1e-6
+        tf, gbs = flops / t / 1e12, nbytes / t / 1e9
+        bound = "mfma" if flops / nbytes > PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS * 1.5 else "hbm"
+        out.append({"site": site, "modules_per_step": m, "us_per_module": round(s["us"] / m, 2),
+                    "us_per_module_events": round(s["ev_us"] / m, 2),
+                    "parts_us": {k: round(v / m, 2) for k, v in s["parts"].items()},
+                    "algorithmic_gflop": round(flops / 1e9, 3), "algorithmic_mb": round(nbytes / 1e6, 3),
+                    "tflops": round(tf, 1), "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 4),
+                    "gb_per_s": round(gbs, 1), "frac_hbm": round(gbs / PEAK_HBM_GBS, 4), "bound": bound,
+                    "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS, 4)})
+    return out
+
+
+def traffic_from_profile(kernel_name):
+    """HBM bytes per launch of a kernel from the committed PMC summary (tools/pmc_traffic.py over two rocprofv3 --pmc passes of
+    this same command; MI355X_MICROARCH.md correction applied).  None when no summary holds that kernel."""
     import glob
-    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    m = re.match(r"igemm_(\d+)x(\d+)_r(\d+)(_vt)?", label)
-    if not files or not m:
+    if not files:
         return None, None
     prof = json.load(open(files[-1]))
-    bm, bn, rp, vt = m.group(1), m.group(2), m.group(3), "true" if m.group(4) else "false"
-    tot = n = 0
-    for k, v in prof.items():       # every ring depth / wave count of the tile family (split-K launches share the kernel)
-        km = re.match(r"igemm_pipe_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\w+), (\d+)(?:, \w+)?>", k)
-        if km and (km.group(1), km.group(2), km.group(3), km.group(4)) == (bm, bn, rp, vt):
-            tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
-            n += v["launches_sampled"]
-    return (tot / n if n else None), os.path.basename(files[-1])
+    short = kernel_name.replace("void ", "").replace("aldm_igemm_detail::", "").split("(")[0]
+    for k, v in prof.items():
+        if k == short or k.endswith(short) or short.endswith(k):
+            return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
 
 
 def cpu_baseline(batch, height, width, rank_lora, max_seconds=30.0):
@@ -133,31 +210,48 @@ def cpu_baseline(batch, height, width, rank_lora, max_seconds=30.0):
                       f"after 1 warm-up; median {med:.2f} s/step"}
 
 
-
-def bench_decode(batch, height, width, reps=3):
-    """VAE latent->mel decode + HiFi-GAN vocoder for the `batch` clips (random-init weights of the real architecture):
-    the remainder of AudioLDMPipeline.__call__ after the loop [REF script/inference/generate_audio.py:47-52]."""
+def bench_pipeline(unet, batch, seconds, nsteps, guidance, seed_off=0):
+    """A REAL `pipe(...)` call, timed end to end: prompt embeddings + initial noise in, host numpy audio out -- set_condition (the
+    time-embedding table of all steps), the `nsteps` graph replays, VAE decode, vocoder and the D2H copy all inside the timed
+    call [REF script/inference/generate_audio.py:47-52] [REF app.py:14].  The first call (which captures the graph) is timed
+    separately.  Random-init weights of the real VAE / vocoder architecture."""
+    from audioldm_with_lora_amd.pipeline import AudioLDMPipeline
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
     from audioldm_with_lora_amd.vae import AutoencoderKL
     from audioldm_with_lora_amd.vocoder import SpeechT5HifiGan
     torch.manual_seed(99)
-    vae, voc = AutoencoderKL().cuda(), SpeechT5HifiGan().cuda()
-    z = torch.randn(batch, 8, height, width, device="cuda")
-    t = {}
-    for name, fn in (("vae_decode_ms", lambda: vae.decode(z).sample), ("vocoder_ms", None)):
-        if fn is None:
-            mel = vae.decode(z).sample.squeeze(1)
-            fn = lambda: voc(mel)
+    pipe = AudioLDMPipeline(AutoencoderKL(), None, None, unet, DDIMScheduler(), SpeechT5HifiGan())
+    pipe.device = torch.device("cuda")
+    pipe.vae.cuda(); pipe.vocoder.cuda()                 # (the UNet is already on the device: keep its packed plan)
+    h = int(seconds * 100) // 4
+    lat, pe, ne = synth_inputs(batch, h, 16, seed_off)
+    call = dict(prompt_embeds=pe, negative_prompt_embeds=ne, audio_length_in_s=seconds, num_inference_steps=nsteps,
+                guidance_scale=guidance)
+    t0 = time.perf_counter()
+    pipe(latents=lat.clone(), **call)
+    first = time.perf_counter() - t0
+    times = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        audio = pipe(latents=lat.clone(), **call).audios
+        times.append(time.perf_counter() - t0)
+    assert audio.shape == (batch, int(seconds * 16000)) and bool((audio == audio).all())
+    # the decode legs alone (eager launches)
+    z = torch.randn(batch, 8, h, 16, device="cuda")
+    legs = {}
+    mel = pipe.vae.decode(z).sample.squeeze(1)
+    for name, fn in (("vae_decode_ms", lambda: pipe.vae.decode(z).sample), ("vocoder_ms", lambda: pipe.vocoder(mel))):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(reps):
-            out = fn()
+        for _ in range(3):
+            fn()
         torch.cuda.synchronize()
-        t[name] = (time.perf_counter() - t0) / reps * 1e3
-    assert torch.isfinite(out).all()
-    del vae, voc
+        legs[name] = (time.perf_counter() - t0) / 3 * 1e3
+    del pipe
     torch.cuda.empty_cache()
-    return t
+    return min(times), first, legs
 
 
 def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
@@ -195,16 +289,13 @@ def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
         tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
+    final = float(loss)
     del tr, unet
     torch.cuda.empty_cache()
     return {"metric": "lora_train_clips_per_sec", "value": round(world * batch * steps / dt, 3), "unit": "10.24s-clips/s",
             "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "per_gpu_batch": batch, "lora_rank": rank_lora,
-            "lora_params": tr_params(rank_lora), "final_loss": round(float(loss), 5),
+            "lora_params": 112640 * rank_lora, "final_loss": round(final, 5),
             "collective": "1 flat fp32 all-reduce/step (RCCL)" if world > 1 else "none"}
-
-
-def tr_params(r):
-    return 112640 * r
 
 
 def main():
@@ -217,7 +308,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--chains", type=int, default=None, help="independent sub-batch chains captured as parallel graph branches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the short LoRA-training measurement")
+    ap.add_argument("--no-train", action="store_true", help="skip the LoRA-training and end-to-end pipeline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--fine", action="store_true", help="print the per-kernel-per-shape table to stderr")
     ap.add_argument("--fp8-attention", action="store_true", help="BASELINE config 5: fp8 (e4m3) Q/K/V/P attention operands")
@@ -269,39 +360,61 @@ def main():
         dt = float(tmax.item())
     assert torch.isfinite(eng.x).all(), "latents diverged"
 
-    decode = None
-    if not args.no_train and rank == 0:
-        eng.graph = None
-        torch.cuda.empty_cache()
-        decode = bench_decode(args.batch, H, W)
-    train = None
-    if not args.no_train:
-        eng.graph = None
-        torch.cuda.empty_cache()
-        train = bench_train(world, rank, rank_lora=(8 if world == 1 else 16))     # config 3 on one GPU, config 4 (rank 16) data-parallel
+    # ---- per-kernel measurement on rank 0 (after the timed region: the tracer must not perturb `value`) ----
+    rows = kernels = span_us = None
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
-        prof = kernel_profile(eng)
-        dom_label, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        total_ms = sum(v["ms"] for v in prof.values())
+        if eng.graph is not None:
+            kernels, span_us = trace_replays(eng)
+        ev_rows = launch_rows(eng)
+        rows = join_trace(ev_rows, kernels) if kernels else None
+        source = "trace"
+        if rows is None:                                     # tracer missing or the sequence did not line up: events only
+            source = "events"
+            rows = [(l, f, b, e, s, e, ["?"]) for l, f, b, e, s in ev_rows]
+            print("[bench] per-kernel durations fall back to hipEvent pairs", file=sys.stderr)
+
+    pipe_t = None
+    if not args.no_train and rank == 0 and not args.fp8_attention and args.chains in (None, 1):
+        pipe_t = bench_pipeline(unet, args.batch, 10.0, NSTEPS, G, seed_off=100 * rank)
+    eng.graph = None
+    train = train16 = None
+    if not args.no_train:
+        torch.cuda.empty_cache()
+        # config 3 (rank 8) on one GPU, config 4 (rank 16, one flat all-reduce per step) data-parallel; on one GPU a short
+        # rank-16 leg also runs so that config 4's per-GPU path (the Rp = 64 kernels) is exercised before any N > 1 run
+        train = bench_train(world, rank, rank_lora=(8 if world == 1 else 16))
+        if world == 1:
+            train16 = bench_train(world, rank, steps=4, warmup=3, rank_lora=16)
+    if rank == 0:
+        agg = aggregate(rows)
+        dom_label, dom = max(agg.items(), key=lambda kv: kv[1]["us"])
+        total_us = sum(v["us"] for v in agg.values())
         if args.fine:
-            for k, v in sorted(kernel_profile(eng, fine=True).items(), key=lambda kv: -kv[1]["ms"]):
-                print(f"{k:64s} {v['launches']:3d}x {v['ms'] * 1e3 / v['launches']:7.1f} us  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:7.1f} TF/s", file=sys.stderr)
+            for k, v in sorted(aggregate(rows, fine=True).items(), key=lambda kv: -kv[1]["us"]):
+                print(f"{k:64s} {v['launches']:3d}x {v['us'] / v['launches']:7.1f} us (events {v['ev_us'] / v['launches']:7.1f})  "
+                      f"{v['flops'] / v['us'] / 1e6 if v['us'] else 0:7.1f} TF/s", file=sys.stderr)
         if args.breakdown:
-            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
-                print(f"{k:32s} {v['launches']:4d} launches {v['ms']:8.3f} ms  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:8.1f} TF/s "
-                      f"{v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:8.1f} GB/s", file=sys.stderr)
-            print(f"eager sum {total_ms:.3f} ms over {sum(v['launches'] for v in prof.values())} launches", file=sys.stderr)
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = traffic_from_profile(dom_label)
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
+                print(f"{k:32s} {v['launches']:4d} launches {v['us'] / 1e3:8.3f} ms  {v['flops'] / v['us'] / 1e6 if v['us'] else 0:8.1f} TF/s "
+                      f"{v['bytes'] / v['us'] / 1e3 if v['us'] else 0:8.1f} GB/s", file=sys.stderr)
+            print(f"kernel sum {total_us / 1e3:.3f} ms over {sum(v['launches'] for v in agg.values())} launches ({source})", file=sys.stderr)
+        achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12
+        traffic, traffic_src = traffic_from_profile(dom["kernel"])
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": (round(traffic) if traffic else None),
                     "traffic_unit": "HBM bytes/launch (PMC, profiles/%s)" % traffic_src if traffic else None,
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
-                    "kernel": dom_label, "launches_per_step": dom["launches"],
-                    "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
-                    "share_of_step": round(dom["ms"] / total_ms, 3)}
+                    "kernel": dom_label, "kernel_symbol": dom["kernel"][:96], "launches_per_step": dom["launches"],
+                    "avg_launch_us": round(dom["us"] / dom["launches"], 2),
+                    "avg_launch_us_events": round(dom["ev_us"] / dom["launches"], 2),
+                    "duration_source": ("device timestamps of the replayed graph's kernels (roctracer; = rocprofv3 --kernel-trace)"
+                                        if source == "trace" else "hipEvent pairs, eager step behind a sleep kernel"),
+                    "share_of_step": round(dom["us"] / total_us, 3),
+                    "launches_per_step_total": len(rows), "kernel_time_sum_ms": round(total_us / 1e3, 4),
+                    "graph_span_ms": round(span_us / 1e3, 4) if span_us else None,
+                    "whole_step_tflops": round(8 * 101.2e9 * (args.batch / 4) / (dt / args.steps) / 1e12, 1)}
         out = {
             "metric": "unet_denoise_steps_per_sec", "value": round(world * args.steps / dt, 3), "unit": "denoise_steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -312,16 +425,22 @@ def main():
                        "per_gpu_batch": args.batch, "parallelism": f"prompt-sharded x{world}", "hip_graph": not args.no_graph, "graph_chains": eng.chains,
                        "sample_steps_per_sec": round(world * args.steps * args.batch / dt, 2)},
             "roofline": roofline,
+            "k1": {"what": "fused-LoRA attention module = QKV GEMM + LoRA (Q|K, V^T) -> flash attention -> out-proj + LoRA + residual; "
+                           "kernel durations only (the two kernel boundaries inside a module are not counted)",
+                   "flops": "b(8NC^2 + 4N^2C + 16NCr)", "bytes": "2bNCs + 4C^2 s + 8Crs, s = 2",
+                   "sites": k1_sites(rows, 2 * args.batch, args.rank)},
         }
         if train is not None:
             out["train"] = train
-        if decode is not None:
-            loop_ms = NSTEPS * dt / args.steps * 1e3
-            total_ms = loop_ms + decode["vae_decode_ms"] + decode["vocoder_ms"]
-            out["end_to_end"] = {"clips_per_sec": round(world * args.batch / (total_ms * 1e-3), 3), "clip_seconds": 10.0,
-                                 "ddim_steps": NSTEPS, "loop_ms": round(loop_ms, 1), "vae_decode_ms": round(decode["vae_decode_ms"], 2),
-                                 "vocoder_ms": round(decode["vocoder_ms"], 2),
-                                 "note": "loop_ms = 200 x the measured step; decode legs run eagerly (not graph-captured)"}
+        if train16 is not None:
+            out["train_rank16"] = train16
+        if pipe_t is not None:
+            call_s, first_s, legs = pipe_t
+            out["end_to_end"] = {"clips_per_sec": round(world * args.batch / call_s, 3), "clip_seconds": 10.0, "ddim_steps": NSTEPS,
+                                 "pipe_call_ms": round(call_s * 1e3, 1), "first_call_ms_incl_capture": round(first_s * 1e3, 1),
+                                 "vae_decode_ms": round(legs["vae_decode_ms"], 2), "vocoder_ms": round(legs["vocoder_ms"], 2),
+                                 "note": "pipe_call_ms = one timed AudioLDMPipeline.__call__ (prompt embeddings + noise in, host audio "
+                                         "out): set_condition + 200 graph replays + VAE decode + vocoder + D2H"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, H, W, args.rank)
         print(json.dumps(out))

@@ -149,6 +149,12 @@ int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* v
                    long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                    void* stream);
 
+/* Same core for a Q that already carries scale * log2(e): the host folds the softmax scale of
+   F.scaled_dot_product_attention (diffusers AttnProcessor2_0 under [REF script/train/train_audioldm_lora.py:539-546]) into the
+   to_q weights and LoRA-B rows when it packs them, so the scores leave the MFMA in their final log2 domain. */
+int aldm_attention_prescaled(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
+                             long long vt_batch_stride, int B, int N, int H, int d, void* out, int out_ld, void* stream);
+
 /* Same, additionally writing the log2-domain log-sum-exp of the scaled scores, lse [B][H][N] fp32 (training). */
 /* Same core with a per-batch-item key count kv_len[B] (int32, device): keys >= kv_len[b] are excluded exactly as an
    additive -inf attention_mask excludes right-padded tokens, and the key loop stops at the last valid tile.  Query
