@@ -45,6 +45,7 @@ class IgemmArgs(C.Structure):
         ("tile", C.c_int),
         ("ring", C.c_int),
         ("defer_reduce", C.c_int),
+        ("rowstat_out", C.c_void_p), ("ln_parts", C.c_void_p), ("ln_nparts", C.c_int),
     ]
 
 

@@ -59,6 +59,9 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
                  "igemm: GEGLU with out2 (pre-activation copy) needs the plain LDS-DMA GEGLU launch (no residual / activation / split-K)");
   ALDM_CHECK_ARG(!p->ln_s || (p->KH == 1 && p->KW == 1 && p->Cin2 == 0 && p->splits <= 1 && (p->Rp == 0 || (p->ln_sa && p->ln_ca))),
                  "igemm: folded LayerNorm needs a 1x1 single-source GEMM without split-K (and ln_sa/ln_ca with LoRA)");
+  ALDM_CHECK_ARG(!p->rowstat_out || (!p->vt && p->splits <= 1 && !p->geglu && p->out_dtype == ALDM_OUT_BF16 && p->Cout % 64 == 0 && !p->out2),
+                 "igemm: rowstat_out needs the standard bf16 epilogue (no V^T / split-K / GEGLU / out2) and Cout %% 64 == 0");
+  ALDM_CHECK_ARG(!p->ln_parts || (p->ln_s && p->ln_nparts > 0 && p->ln_nparts <= 64), "igemm: ln_parts needs ln_s and 1..64 partials per row");
   ALDM_CHECK_ARG(p->ring == 0 || (p->ring >= 2 && p->ring <= 4), "igemm: ring must be 0 (auto) or 2..4");
   ALDM_CHECK_ARG(p->in_dilate == 0 || (p->in_dilate == 2 && p->UH == 0), "igemm: in_dilate must be 0 or 2 (and excludes UH/UW)");
 
@@ -95,6 +98,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.lb_bytes = (unsigned)(2ull * p->Cout * p->Rp);
     d.fd_ohw = make_fastdiv((unsigned)d.OHW); d.fd_ow = make_fastdiv((unsigned)d.OW); d.fd_halo = make_fastdiv((unsigned)d.OW + 2u);
     d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
+    d.rowstat = p->rowstat_out; d.ln_parts = p->ln_parts; d.ln_np = p->ln_nparts;
 #ifdef ALDM_DIAG
     d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer
 #else
@@ -114,7 +118,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_HALO_128x128:
     case ALDM_TILE_HALO_64x128:
-      if (p->Rp || vt) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T"); return ALDM_E_UNSUPPORTED; }
+      if (p->Rp || vt || p->rowstat_out) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics"); return ALDM_E_UNSUPPORTED; }
       rc = aldm_launch_halo(d, tile, p->ring, st);
       break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;

@@ -60,6 +60,8 @@ struct IgemmDev {
   unsigned long long* diag;   // diagnostic builds only
   FastDiv fd_ohw, fd_ow, fd_halo;   // fd_halo: / (OW + 2), halo kernel only
   const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;   // LayerNorm folded into the GEMM (see below)
+  float* rowstat;             // producer side of the LayerNorm hand-over: [M][tiles_n][2] (sum, sum of squares) per output row and N-tile
+  const float* ln_parts; int ln_np;   // consumer side: the producer's table, ln_np partial pairs per row
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -347,6 +349,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         if (vec) *reinterpret_cast<bf16x8*>(o) = t;       // (non-temporal stores: -7 % on isolated GEMMs, +1.2 % on the whole step)
         else
           for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = t[q];
+        if (p.rowstat) {
+          // LayerNorm hand-over: this row's sum / sum of squares over the tile's BN columns, of the values AS STORED (bf16).
+          // The GPR threads of a row are consecutive lanes of one wave and are all active together (host-checked N % BN == 0).
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const float f = (float)t[q]; s1 += f; s2 = fmaf(f, f, s2); }
+#pragma unroll
+          for (int o2 = 1; o2 < GPR; o2 <<= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
+          if ((tid % GPR) == 0) {
+            float* dst = p.rowstat + ((long long)(m0 + r) * p.tiles_n + n0 / BN) * 2;
+            dst[0] = s1;
+            dst[1] = s2;
+          }
+        }
       }
     }
   };
@@ -398,17 +414,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       const int n = n0 + rn, m = m0 + cm;
       if (n >= p.N || m >= p.M) continue;
       const float bb = p.bias ? p.bias[n] : 0.f;
+      const float lsn = lnst ? p.ln_s[n] : 0.f;
       const float* src = Cs + rn * E::LDT + cm;
       const int b = fdiv(m, p.fd_ohw), pix = m - b * p.OHW;
       bf16* o = p.vt + (long long)b * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pix;
       if (m + 7 < p.M && pix + 7 < p.OHW && ((p.vt_ld & 7) == 0) && ((pix & 7) == 0) && ((p.vt_bs & 7) == 0)) {
         bf16x8 t;
+        float mu8[8], rs8[8];
+        if (lnst) {                                              // cm is a multiple of 8: four 16-byte LDS reads
+          const f32x4 m0v = *reinterpret_cast<const f32x4*>(lnst + cm), m1v = *reinterpret_cast<const f32x4*>(lnst + cm + 4);
+          const f32x4 r0v = *reinterpret_cast<const f32x4*>(lnst + BM + cm), r1v = *reinterpret_cast<const f32x4*>(lnst + BM + cm + 4);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float val = src[q];
-          if (lnst) val = lnst[BM + cm + q] * (val - lnst[cm + q] * p.ln_s[n]);
-          t[q] = (bf16)(val + bb);
+          for (int q = 0; q < 4; ++q) { mu8[q] = m0v[q]; mu8[4 + q] = m1v[q]; rs8[q] = r0v[q]; rs8[4 + q] = r1v[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { mu8[q] = 0.f; rs8[q] = 1.f; }
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (bf16)(rs8[q] * (src[q] - mu8[q] * lsn) + bb);
         *reinterpret_cast<bf16x8*>(o) = t;
       } else {
         for (int q = 0; q < 8; ++q) {
@@ -416,7 +439,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
           if (mq >= p.M) break;
           const int bq = fdiv(mq, p.fd_ohw), pq = mq - bq * p.OHW;
           float val = src[q];
-          if (lnst) val = lnst[BM + cm + q] * (val - lnst[cm + q] * p.ln_s[n]);
+          if (lnst) val = lnst[BM + cm + q] * (val - lnst[cm + q] * lsn);
           p.vt[(long long)bq * p.vt_bs + (long long)(n - p.vt_col0) * p.vt_ld + pq] = (bf16)(val + bb);
         }
       }
@@ -441,39 +464,48 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     return;
   }
   if (!SLEAN && (GLEAN || p.geglu)) {
-    // image columns come in blocks of (16 value | 16 gate); 8 output columns = 8 values and their 8 gates
-    for (int g = tid; g < BM * (BN / 16); g += NT) {
-      const int r = g / (BN / 16), jo = (g - r * (BN / 16)) * 8;        // jo: output column inside the tile
-      const int cv = ((jo >> 4) << 5) + (jo & 15);                       // value column inside the tile
-      const int m = m0 + r, nv = n0 + cv;
-      if (m >= p.M || nv >= p.N) continue;
+    // image columns come in blocks of (16 value | 16 gate); 8 output columns = 8 values and their 8 gates.  A thread keeps ONE
+    // column group and walks down the rows, so the bias / LayerNorm column vectors are four 16-byte loads per thread, once
+    // (per-element scalar loads of them were 32-64 global loads per thread: 3-13 us of the feed-forward GEMMs' epilogue).
+    constexpr int CG = BN / 16, RS = NT / CG;
+    static_assert(NT % CG == 0 && BM % RS == 0, "GEGLU row walk");
+    const int jo = (tid % CG) * 8;                                       // output column inside the tile
+    const int cv = ((jo >> 4) << 5) + (jo & 15);                         // value column inside the tile
+    const int nv = n0 + cv;
+    if (nv >= p.N) return;                                               // N % 32 == 0: the whole (value | gate) group is in or out
+    float bv[8], bg[8], sv[8], sg[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bv[q] = bg[q] = sv[q] = sg[q] = 0.f;
+    if (p.bias) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.bias + nv), a1 = *reinterpret_cast<const f32x4*>(p.bias + nv + 4);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.bias + nv + 16), g1 = *reinterpret_cast<const f32x4*>(p.bias + nv + 20);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { bv[q] = a0[q]; bv[4 + q] = a1[q]; bg[q] = g0[q]; bg[4 + q] = g1[q]; }
+    }
+    if (lnst) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.ln_s + nv), a1 = *reinterpret_cast<const f32x4*>(p.ln_s + nv + 4);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_s + nv + 16), g1 = *reinterpret_cast<const f32x4*>(p.ln_s + nv + 20);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sv[q] = a0[q]; sv[4 + q] = a1[q]; sg[q] = g0[q]; sg[4 + q] = g1[q]; }
+    }
+    for (int r = tid / CG; r < BM; r += RS) {
+      const int m = m0 + r;
+      if (m >= p.M) break;
       const float* src = Cs + r * E::LD + cv;
-      float v[8];
+      const float mu = lnst ? lnst[r] : 0.f, rs = lnst ? lnst[BM + r] : 1.f;
+      float val[8], gate[8], v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        float val = src[q], gate = src[16 + q];
-        if (lnst) {
-          val = lnst[BM + r] * (val - lnst[r] * p.ln_s[nv + q]);
-          gate = lnst[BM + r] * (gate - lnst[r] * p.ln_s[nv + 16 + q]);
-        }
-        if (p.bias) { val += p.bias[nv + q]; gate += p.bias[nv + 16 + q]; }
-        v[q] = val * gelu_erf_f(gate);
+        val[q] = rs * (src[q] - mu * sv[q]) + bv[q];
+        gate[q] = rs * (src[16 + q] - mu * sg[q]) + bg[q];
+        v[q] = val[q] * gelu_erf_f(gate[q]);
       }
       if constexpr (GLEAN) {
         if (p.out2) {   // training: also keep the pre-activation projection h [M][N] (packed value | gate columns) for the backward
           bf16* hrow = p.out2 + (long long)m * p.N + nv;
           bf16x8 hv, hg;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            float val = src[q], gate = src[16 + q];
-            if (lnst) {
-              val = lnst[BM + r] * (val - lnst[r] * p.ln_s[nv + q]);
-              gate = lnst[BM + r] * (gate - lnst[r] * p.ln_s[nv + 16 + q]);
-            }
-            if (p.bias) { val += p.bias[nv + q]; gate += p.bias[nv + 16 + q]; }
-            hv[q] = (bf16)val;
-            hg[q] = (bf16)gate;
-          }
+          for (int q = 0; q < 8; ++q) { hv[q] = (bf16)val[q]; hg[q] = (bf16)gate[q]; }
           *reinterpret_cast<bf16x8*>(hrow) = hv;
           *reinterpret_cast<bf16x8*>(hrow + 16) = hg;
         }
@@ -971,8 +1003,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   constexpr int TPR = NT / BM;                       // threads per tile row
   constexpr int CPT = 8 / TPR;                            // 16-byte chunks of a 64-wide K-tile per thread
   const bool lnf = (!LEAN || VT) && p.ln_s != nullptr;   // LEAN non-V^T launches never carry a folded LayerNorm (host-checked)
+  const bool ln_hand = lnf && p.ln_parts != nullptr;     // statistics handed over by the producer of the activations (rowstat_out)
   const int ln_row = tid / TPR, ln_c0 = (tid % TPR) * CPT;
   float ln_sum = 0.f, ln_sq = 0.f;
+  if (ln_hand && tid < BM) {                             // issued here, consumed after the K loop: the loads fly under the ring
+    const float* pp = p.ln_parts + (long long)min(m0 + tid, p.M - 1) * (p.ln_np * 2);
+    for (int j = 0; j < p.ln_np; ++j) {
+      const float2 v2 = *reinterpret_cast<const float2*>(pp + 2 * j);
+      ln_sum += v2.x;
+      ln_sq += v2.y;
+    }
+  }
   auto ln_accum = [&](const char* As) {
 #pragma unroll
     for (int cc = 0; cc < CPT; ++cc) {
@@ -1000,7 +1041,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
 #ifdef ALDM_DIAG
       ALDM_STAMP(t3)
 #endif
-      if (lnf) ln_accum(smem + st * STAGE);
+      if (lnf && !ln_hand) ln_accum(smem + st * STAGE);
       mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 0, true);
       mma_step(vtf, smem + st * STAGE, smem + st * STAGE + BM * 128, 1, true);
 #ifdef ALDM_DIAG
@@ -1020,13 +1061,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   __builtin_amdgcn_s_barrier();
   float* const lnst = lnf ? reinterpret_cast<float*>(smem + LDS_MAIN) : nullptr;   // [2][BM]: mean, rstd (past every other image)
   if (lnf) {
+    const float invk = 1.f / (float)(p.Ctot * p.KH * p.KW);
+    if (ln_hand) {
+      if (tid < BM) {
+        const float mu = ln_sum * invk;
+        lnst[tid] = mu;
+        lnst[BM + tid] = rsqrtf(fmaxf(ln_sq * invk - mu * mu, 0.f) + p.ln_eps);
+      }
+    } else {
 #pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) { ln_sum += __shfl_xor(ln_sum, o, 64); ln_sq += __shfl_xor(ln_sq, o, 64); }
-    if ((tid % TPR) == 0) {
-      const float invk = 1.f / (float)(p.Ctot * p.KH * p.KW);
-      const float mu = ln_sum * invk;
-      lnst[ln_row] = mu;
-      lnst[BM + ln_row] = rsqrtf(fmaxf(ln_sq * invk - mu * mu, 0.f) + p.ln_eps);
+      for (int o = 1; o < TPR; o <<= 1) { ln_sum += __shfl_xor(ln_sum, o, 64); ln_sq += __shfl_xor(ln_sq, o, 64); }
+      if ((tid % TPR) == 0) {
+        const float mu = ln_sum * invk;
+        lnst[ln_row] = mu;
+        lnst[BM + ln_row] = rsqrtf(fmaxf(ln_sq * invk - mu * mu, 0.f) + p.ln_eps);
+      }
     }
     __syncthreads();
   }
@@ -1042,8 +1091,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
         const int col = (wn * RT_W + t) * 16 + lq * 4;
         if (lnf) {   // T'' = t - mean sA + cA / rstd : the epilogue's rstd (acc - mean s) + c then also fixes the LoRA term
           const float mu = lnst[r], irs = 1.f / lnst[BM + r];
+          const f32x4 sa4 = *reinterpret_cast<const f32x4*>(p.ln_sa + col), ca4 = *reinterpret_cast<const f32x4*>(p.ln_ca + col);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tacc[i][t][e] = tacc[i][t][e] - mu * p.ln_sa[col + e] + p.ln_ca[col + e] * irs;
+          for (int e = 0; e < 4; ++e) tacc[i][t][e] = tacc[i][t][e] - mu * sa4[e] + ca4[e] * irs;
         }
         bf16x4 tv = {(bf16)tacc[i][t][0], (bf16)tacc[i][t][1], (bf16)tacc[i][t][2], (bf16)tacc[i][t][3]};
         *reinterpret_cast<bf16x4*>(As + r * 128 + swz(r, col >> 3) * 16 + (col & 7) * 2) = tv;
@@ -1129,6 +1179,10 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
   else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S, EPI>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm")) return rc;
+  if (d.rowstat && d.N % BN != 0) {
+    aldm_set_error("igemm: rowstat_out needs Cout %d to be a multiple of the tile width %d", d.N, BN);
+    return ALDM_E_ARG;
+  }
   if (VT && d.vt_col0 % BN != 0) {
     aldm_set_error("igemm: vt_col0 %d must be a multiple of the tile width %d", d.vt_col0, BN);
     return ALDM_E_ARG;

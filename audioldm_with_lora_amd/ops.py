@@ -389,7 +389,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False):
+         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
@@ -397,7 +397,11 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     bf16 output is never written (ResnetBlock2D.conv1 -> norm2 -> SiLU).  gn_keep=True returns (convolution, its GroupNorm)
     -- ResnetBlock2D.conv2 (+ shortcut `res`) in front of a Transformer2DModel's norm: the block output stays on the residual
     stream and the fused kernel writes both.  defer=True: the same for a norm that is launched later by the caller -- returns
-    a Deferred (see there) when the launch is split-K, else the tensor as usual."""
+    a Deferred (see there) when the launch is split-K, else the tensor as usual.
+
+    LayerNorm hand-over (BasicTransformerBlock: h -> LayerNorm -> projection): rowstats=True returns (out, stats), stats fp32
+    [M, N / BN, 2] = per-row partial (sum, sum of squares) written by the epilogue; a consumer packed with pack_linear_ln takes
+    them as ln_parts= and derives mean / rstd from them -- no LayerNorm launch, no statistics pass in either GEMM's K loop."""
     global _PENDING
     if _PENDING is not None:
         raise _lib.AldmError("conv: a deferred split-K reduce is pending -- its consumer groupnorm() must be the next launch")
@@ -446,6 +450,17 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         a.ln_s, a.ln_eps = pw.ln_s.data_ptr(), pw.ln_eps
         if pw.Rp:
             a.ln_sa, a.ln_ca = pw.ln_sa.data_ptr(), pw.ln_ca.data_ptr()
+        if ln_parts is not None:
+            assert ln_parts.dtype == torch.float32 and ln_parts.is_contiguous() and ln_parts.dim() == 3 and ln_parts.shape[2] == 2
+            assert ln_parts.shape[0] == B * IH * IW and KH == 1 and KW == 1, "ln_parts: one row of partials per GEMM row"
+            a.ln_parts, a.ln_nparts = ln_parts.data_ptr(), ln_parts.shape[1]
+    elif ln_parts is not None:
+        raise _lib.AldmError("conv: ln_parts without a LayerNorm-folded weight pack (pack_linear_ln)")
+    if rowstats:
+        if vt is not None or pw.geglu or out_f32 or out2 is not None or pw.N % 64 or gn is not None or defer:
+            raise _lib.AldmError("conv: rowstats needs the standard bf16 epilogue and N % 64 == 0")
+        if splits is None:
+            splits = 1                                   # the statistics come out of the (single) epilogue
     if rowbias is not None:
         assert rowbias.dtype == torch.float32
         a.rowbias, a.rowbias_ld = rowbias.data_ptr(), rowbias_ld
@@ -478,7 +493,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if tile == 0 and ring == 0:
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
-        sfx = ("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "")
+        sfx = ("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "") + (" rs" if rowstats else "") + (" lp" if ln_parts is not None else "")
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
@@ -502,6 +517,13 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if not ring:
         bm, bn = TILE_DIMS[tile]
         ring = pick_ring(tile, bm, bn, pw.Rp, math.ceil(M / bm) * math.ceil(pw.N / bn) * max(1, splits), ktiles)
+    stats = None
+    if rowstats:
+        if tile in HALO_ROWS or pw.N % TILE_DIMS[tile][1] or splits != 1:
+            tile, splits = _lib.TILE_64x64, 1             # always legal: N % 64 == 0 was checked above
+            ring = pick_ring(tile, 64, 64, pw.Rp, math.ceil(M / 64) * (pw.N // 64), ktiles)
+        stats = torch.empty(M, pw.N // TILE_DIMS[tile][1], 2, dtype=torch.float32, device=x.device)
+        a.rowstat_out = stats.data_ptr()
     a.splits = splits
     if splits > 1:
         a.workspace = _workspace(splits * M * pw.N * 4, x.device).data_ptr()
@@ -523,7 +545,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             if eff > 1:
                 _PENDING = Deferred(out, a.workspace, eff, a.bias, a.rowbias, a.rowbias_ld, a.res, (pw, rowbias, res))
                 return _PENDING
-            return out
+            return (out, stats) if rowstats else out
         gamma, beta, groups, eps, act = gn
         if eff <= 1:
             y = groupnorm(out, gamma, beta, groups, eps, act)
@@ -553,6 +575,8 @@ def linear(x2d: torch.Tensor, pw: PackedW, **kw):
     M, K = x2d.shape
     out = kw.pop("out", None)
     y = conv(x2d.view(1, 1, M, K), pw, out=(None if out is None else out), **kw)
+    if kw.get("rowstats"):
+        return (y[0] if out is not None else y[0].view(M, -1)), y[1]
     return y if out is not None else y.view(M, -1)
 
 

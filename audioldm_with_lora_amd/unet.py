@@ -169,10 +169,12 @@ def pack_resnet(r: ResnetBlock2D):
         groups=r.groups, eps=r.eps, cout=r.cout, temb_off=0)
 
 
-# The LayerNorm fold trades a ~3-5 us LayerNorm launch for in-kernel row statistics (extra LDS reads per K-tile) and a longer
-# epilogue.  Measured in a replayed graph (tools/bench_qkv_graph.py): it wins at C = 640 (N = 64 tokens: -0.7 us on the QKV GEMM,
-# -1.5 us on the GEGLU GEMM), is a wash for the C = 256 QKV GEMM and LOSES 2.7-3.5 us on the C = 384 QKV / C = 256 GEGLU GEMMs.
-LN_FOLD_MIN_C = 512
+# LayerNorm folded into the consuming GEMM (ops.pack_linear_ln).  With the row statistics accumulated inside the consumer's K loop
+# the fold only paid at C = 640 (measured in a replayed graph, tools/bench_qkv_graph.py: -0.7 / -1.5 us there, +2.7-3.5 us on the
+# C = 384 QKV and C = 256 GEGLU GEMMs: every one of the consumer's N-tiles re-derives the same statistics).  Now the PRODUCER of the
+# hidden state hands them over (ops.conv rowstats= / ln_parts=): its epilogue writes per-row partial sums, the consumer's prologue
+# folds them -- neither GEMM's K loop pays, and all 48 LayerNorm launches of a UNet forward are gone at every width.
+LN_FOLD_MIN_C = 64
 
 
 def pack_attention(a: Attention, ln=None):
@@ -254,15 +256,17 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=No
     return ops.conv(h, P.conv2, pad=(1, 1), res=xs, defer=(defer or False))
 
 
-def run_attention(P, hn, h_res, B, N, fp8=False):
-    """hn = LayerNorm(h) [B*N, C]; returns h_res + to_out(attention(q, k, v)) with LoRA fused in both GEMMs."""
+def run_attention(P, hn, h_res, B, N, fp8=False, ln_parts=None, rowstats=False):
+    """hn = LayerNorm(h) [B*N, C] (or h itself when the norm is folded into the QKV GEMM; ln_parts = its row statistics from the
+    producer of h); returns h_res + to_out(attention(q, k, v)) with LoRA fused in both GEMMs -- and, with rowstats, the row
+    statistics of that sum for the LayerNorm that follows."""
     C = P.c
     npad = (N + 7) // 8 * 8
     vt = torch.empty(B, C, npad, dtype=torch.bfloat16, device=hn.device)
     ops.SITE = f"attn C{C} N{N}"                      # bench.py prices these three launches as ONE fused-LoRA attention module (K1)
-    qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad)
+    qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad, ln_parts=ln_parts)
     a = ops.attention(qk.view(B * N, 2 * C), vt, B, N, P.heads, P.d, fp8=fp8, prescaled=True)
-    y = ops.linear(a, P.out, res=h_res)
+    y = ops.linear(a, P.out, res=h_res, rowstats=rowstats)
     ops.SITE = None
     return y
 
@@ -277,11 +281,23 @@ def run_transformer(P, x, fp8=False, xn=None, defer=None):
     B, H, W, C = x.shape
     N = H * W
     h = xn if xn is not None else ops.groupnorm(x, *transformer_gn(P))
-    h = ops.conv(h, P.proj_in).view(B * N, C)
-    # LayerNorms are folded into the consuming GEMM where possible (row statistics computed in-kernel)
-    h = run_attention(P.attn1, h if P.attn1.ln_folded else ops.layernorm(h, *P.ln[0]), h, B, N, fp8)
-    h = run_attention(P.attn2, h if P.attn2.ln_folded else ops.layernorm(h, *P.ln[1]), h, B, N, fp8)   # encoder_hidden_states=None: self-attention
-    g = ops.linear(h if P.ff1.ln_s is not None else ops.layernorm(h, *P.ln[2]), P.ff1)
+    # The three LayerNorms are folded into the GEMMs that consume them; each producer of the hidden state (proj_in, the two
+    # out-projections) hands the row statistics over (st): no LayerNorm launch, no statistics pass inside a K loop.
+    f1, f2, f3 = P.attn1.ln_folded, P.attn2.ln_folded, P.ff1.ln_s is not None
+    st = None
+    h = ops.conv(h, P.proj_in, rowstats=f1)
+    if f1:
+        h, st = h
+    h = h.view(B * N, C)
+    h = run_attention(P.attn1, h if f1 else ops.layernorm(h, *P.ln[0]), h, B, N, fp8, ln_parts=st, rowstats=f2)
+    st = None
+    if f2:
+        h, st = h
+    h = run_attention(P.attn2, h if f2 else ops.layernorm(h, *P.ln[1]), h, B, N, fp8, ln_parts=st, rowstats=f3)   # encoder_hidden_states=None: self-attention
+    st = None
+    if f3:
+        h, st = h
+    g = ops.linear(h if f3 else ops.layernorm(h, *P.ln[2]), P.ff1, ln_parts=st)
     if P.ff2_proj is not None:                                # ff2 and proj_out as ONE GEMM over the virtual concat [g | h]
         return ops.conv(g.view(B, H, W, 4 * C), P.ff2_proj, x2=h.view(B, H, W, C), res=x, defer=(defer or False))
     h = ops.linear(g, P.ff2, res=h)

@@ -83,16 +83,21 @@ def trace_replays(engine, reps=6):
             torch.cuda.synchronize()
         evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name and "Memset" not in e.name]
         evs.sort(key=lambda e: e.time_range.start)
-        if not evs or len(evs) % reps:
+        # cut the stream into replays at the step's first kernel (gather_row); keep the complete ones (the tracer may drop or add
+        # a few events at the edges of its window)
+        starts = [i for i, e in enumerate(evs) if "gather_row_kernel" in e.name]
+        segs = [evs[a:b] for a, b in zip(starts, starts[1:] + [len(evs)])]
+        if not segs:
+            print(f"[bench] kernel trace: no replay boundary among {len(evs)} device events", file=sys.stderr)
             return None, None
-        n = len(evs) // reps
-        per = []
-        for i in range(n):
-            names = {evs[r * n + i].name for r in range(reps)}
-            if len(names) != 1:
-                return None, None
-            per.append((evs[i].name, sum(evs[r * n + i].time_range.elapsed_us() for r in range(reps)) / reps))
-        span = sum(evs[r * n + n - 1].time_range.end - evs[r * n].time_range.start for r in range(reps)) / reps
+        lens = sorted(len(g) for g in segs)
+        n = lens[len(lens) // 2]
+        segs = [g for g in segs if len(g) == n and [e.name for e in g] == [e.name for e in segs[[len(x) for x in segs].index(n)]]]
+        if len(segs) < 2:
+            print(f"[bench] kernel trace: replays do not line up ({lens})", file=sys.stderr)
+            return None, None
+        per = [(segs[0][i].name, sum(g[i].time_range.elapsed_us() for g in segs) / len(segs)) for i in range(n)]
+        span = sum(g[-1].time_range.end - g[0].time_range.start for g in segs) / len(segs)
         return per, span
     except Exception as ex:                                  # measurement aid only: never let it take the bench line down
         print(f"[bench] kernel trace unavailable: {type(ex).__name__}: {ex}", file=sys.stderr)
@@ -104,6 +109,7 @@ def join_trace(rows, kernels):
     out, k = [], 0
     for label, flops, nbytes, ev_us, site in rows:
         if k >= len(kernels):
+            print(f"[bench] kernel trace: {len(kernels)} kernels per replay < {len(rows)} launch rows", file=sys.stderr)
             return None
         us, names = kernels[k][1], [kernels[k][0]]
         k += 1
@@ -112,7 +118,10 @@ def join_trace(rows, kernels):
             names.append(kernels[k][0])
             k += 1
         out.append((label, flops, nbytes, ev_us, site, us, names))
-    return out if k == len(kernels) else None
+    if k != len(kernels):
+        print(f"[bench] kernel trace: {len(kernels)} kernels per replay, {k} matched to {len(rows)} launch rows; next: {kernels[k][0][:80]}", file=sys.stderr)
+        return None
+    return out
 
 
 def aggregate(rows, fine=False):

@@ -95,6 +95,13 @@ typedef struct {
   int defer_reduce;         /* split-K only: leave the partial tiles in `workspace` and launch no reduce -- the consumer sums
                                them itself and adds bias / rowbias / res (aldm_groupnorm_partials: ResnetBlock2D convs
                                in front of a GroupNorm) */
+  /* LayerNorm statistics handed from one GEMM to the next (BasicTransformerBlock: h -> norm -> projection).  The producer of h
+     (bf16 output, standard epilogue, Cout a multiple of its tile width BN) writes, per output row and per N-tile, the sum and
+     the sum of squares of the row's bf16-rounded values: rowstat_out [M][Cout / BN][2] fp32.  The consumer (ln_s != NULL)
+     takes that table as ln_parts [M][ln_nparts][2] and derives mean / rstd from it instead of accumulating them from its
+     activation tiles in the K loop -- the LayerNorm launch disappears and no GEMM pays for the statistics twice. */
+  float* rowstat_out;
+  const float* ln_parts;  int ln_nparts;
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
