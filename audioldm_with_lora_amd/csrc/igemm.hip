@@ -29,7 +29,7 @@ extern "C" size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p) {
 
 extern "C" int aldm_igemm_effective_splits(const aldm_igemm_t* p) {
   if (!p || p->splits <= 1) return 1;
-  const int nkt = cdiv(p->KH * p->KW * (p->Cin + p->Cin2), BK);
+  const int nkt = cdiv(p->KH * p->KW * (p->Cin + p->Cin2), BK) + (p->x3 ? (p->Cin3 + (p->x4 ? p->Cin4 : 0)) / BK : 0);
   int splits = p->splits > nkt ? nkt : p->splits;
   const int per = cdiv(nkt, splits);
   return cdiv(nkt, per);
@@ -43,7 +43,13 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   ALDM_CHECK_ARG(p->KH > 0 && p->KW > 0, "igemm: bad filter");
   const int Ctot = p->Cin + p->Cin2;
   const int Ktot = p->KH * p->KW * Ctot;
-  ALDM_CHECK_ARG(p->Kpad % BK == 0 && p->Kpad >= Ktot, "igemm: Kpad %d must be a multiple of 64 and >= %d", p->Kpad, Ktot);
+  const int Cext = p->x3 ? p->Cin3 + (p->x4 ? p->Cin4 : 0) : 0;
+  ALDM_CHECK_ARG(p->Kpad % BK == 0 && p->Kpad >= Ktot + Cext, "igemm: Kpad %d must be a multiple of 64 and >= %d", p->Kpad, Ktot + Cext);
+  ALDM_CHECK_ARG(!p->x3 || (p->Cin3 > 0 && p->Cin3 % 64 == 0 && (!p->x4 || (p->Cin4 > 0 && p->Cin4 % 64 == 0)) && Ktot % 64 == 0 &&
+                            p->Cin % 64 == 0 && p->Cin2 % 64 == 0 && p->in_act == ALDM_ACT_NONE && !p->ln_s && !p->vt && !p->geglu &&
+                            p->in_dilate == 0 && p->Rp == 0),
+                 "igemm: the fused 1x1 second-source segment (x3 | x4) needs the plain LDS-DMA path: every channel count and KH*KW*(Cin+Cin2) a multiple of 64");
+  ALDM_CHECK_ARG(p->x3 || !p->x4, "igemm: x4 without x3");
   ALDM_CHECK_ARG(p->Rp == 0 || p->Rp == 32 || p->Rp == 64, "igemm: Rp must be 0/32/64");
   ALDM_CHECK_ARG(p->Rp == 0 || (p->lora_a && p->lora_b), "igemm: Rp without lora_a/lora_b");
   ALDM_CHECK_ARG(!p->geglu || (p->Cout % 32 == 0 && !p->rowbias), "igemm: GEGLU needs Cout %% 32 == 0");
@@ -81,7 +87,9 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   d.out_f32 = p->out_dtype == ALDM_OUT_F32; d.out_ld = p->out_ld;
   d.out_bs = p->out_batch_stride; d.out_ps = p->out_pix_stride > 0 ? p->out_pix_stride : 1; d.out_po = p->out_pix_offset;
   d.vt_col0 = p->vt_col0; d.vt_ld = p->vt_ld; d.vt_bs = p->vt_batch_stride;
-  d.nkt = cdiv(Ktot, BK);
+  d.x3 = (const bf16*)p->x3; d.x4 = (const bf16*)p->x4; d.Cin3 = p->x3 ? p->Cin3 : 0; d.Cin4 = (p->x3 && p->x4) ? p->Cin4 : 0;
+  d.C3tot = d.Cin3 + d.Cin4;
+  d.nkt = cdiv(Ktot, BK) + d.C3tot / BK;
   d.splits = p->splits > 1 ? p->splits : 1;
   if (d.splits > d.nkt) d.splits = d.nkt;
   d.kt_per_split = cdiv(d.nkt, d.splits);
@@ -91,6 +99,9 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     const unsigned long long xb = 2ull * p->B * p->IH * p->IW * p->Cin, x2b = 2ull * p->B * p->IH * p->IW * p->Cin2;
     const unsigned long long wb = 2ull * p->Cout * p->Kpad, lb = 2ull * p->Rp * p->Kpad;
     ALDM_CHECK_ARG(wb < 0xFFFFFFFFull, "igemm: weight matrix too large for 32-bit offsets");
+    const unsigned long long x3b = 2ull * p->B * p->OH * p->OW * d.Cin3, x4b = 2ull * p->B * p->OH * p->OW * d.Cin4;
+    ALDM_CHECK_ARG(x3b < 0x80000000ull && x4b < 0x80000000ull, "igemm: x3 / x4 too large for 32-bit offsets");
+    d.x3_bytes = (unsigned)x3b; d.x4_bytes = (unsigned)x4b;
     d.x_bytes = xb < 0xFFFFFFFFull ? (unsigned)xb : 0xFFFFFFFFu;
     d.x2_bytes = x2b < 0xFFFFFFFFull ? (unsigned)x2b : 0xFFFFFFFFu;
     d.w_bytes = (unsigned)wb;
@@ -118,7 +129,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_HALO_128x128:
     case ALDM_TILE_HALO_64x128:
-      if (p->Rp || vt || p->rowstat_out) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics"); return ALDM_E_UNSUPPORTED; }
+      if (p->Rp || vt || p->rowstat_out || p->x3) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics / second-source segment"); return ALDM_E_UNSUPPORTED; }
       rc = aldm_launch_halo(d, tile, p->ring, st);
       break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;

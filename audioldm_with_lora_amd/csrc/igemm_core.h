@@ -60,6 +60,7 @@ struct IgemmDev {
   unsigned long long* diag;   // diagnostic builds only
   FastDiv fd_ohw, fd_ow, fd_halo;   // fd_halo: / (OW + 2), halo kernel only
   const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;   // LayerNorm folded into the GEMM (see below)
+  const bf16* x3; const bf16* x4; int Cin3, Cin4, C3tot; unsigned x3_bytes, x4_bytes;   // fused 1x1 second-source segment (shortcut)
   float* rowstat;             // producer side of the LayerNorm hand-over: [M][tiles_n][2] (sum, sum of squares) per output row and N-tile
   const float* ln_parts; int ln_np;   // consumer side: the producer's table, ln_np partial pairs per row
 };
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   // the swizzle's inverse image (the XOR is an involution and depends on (row >> 1) & 7 only, not on pass)
   const int rbase = tid >> 3;
   const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);
-  int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES];
+  int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES], a_m[A_PASSES];
 #pragma unroll
   for (int ps = 0; ps < A_PASSES; ++ps) {
     const int m = min(m0 + rbase + RPP * ps, p.M - 1);
@@ -847,6 +848,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
     a_pix0[ps] = b * p.IH * p.IW;
     a_ih0[ps] = oh * p.sh - p.ph;
     a_iw0[ps] = ow * p.sw - p.pw;
+    a_m[ps] = m;                                  // the fused 1x1 segment reads output pixel m of x3 | x4
   }
   unsigned b_off[B_PASSES];
 #pragma unroll
@@ -855,15 +857,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
     const int row = ps < W_PASSES ? min(n0 + r, p.N - 1) : r - BN;
     b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
   }
-  // scalar K cursor
+  // scalar K cursor.  Past the last filter tap (s_kh == KH) lies the optional fused 1x1 segment over x3 | x4 (ResnetBlock2D's
+  // shortcut riding in conv2's launch): same cursor, C3tot channels, the output pixel itself as the gather position.
   int s_kh, s_kw, s_c0;
   {
-    const int k = kt0 * BK;
-    const int tap = k / p.Ctot;
-    s_c0 = k - tap * p.Ctot;
-    s_kh = tap / p.KW;
-    s_kw = tap - s_kh * p.KW;
+    const int k = kt0 * BK, kmain = p.KH * p.KW * p.Ctot;
+    if (k >= kmain && p.C3tot > 0) {
+      s_kh = p.KH; s_kw = 0; s_c0 = k - kmain;
+    } else {
+      const int tap = k / p.Ctot;
+      s_c0 = k - tap * p.Ctot;
+      s_kh = tap / p.KW;
+      s_kw = tap - s_kh * p.KW;
+    }
   }
+  // (scalar copies: a select between two FIELDS of the by-value kernel argument becomes a select between their addresses, which
+  //  forces the whole argument struct into scratch memory -- measured: 864 B of scratch per lane and every GEMM 4-6x slower)
+  const int k_cin = p.Cin, k_cin2 = p.Cin2, k_ctot = p.Ctot, k_cin3 = p.Cin3, k_cin4 = p.Cin4, k_c3tot = p.C3tot;
   bool s_fresh = true;     // tap or source changed: per-lane offsets must be recomputed
   unsigned cur_off[A_PASSES];
   int a_soff = 0, b_soff = kt0 * BK * 2;
@@ -872,32 +882,52 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   auto issue = [&](int kt, int stage) {
     char* sbase = smem + stage * STAGE + wave * 1024;   // + pass * 4096: this wave's 8 rows of the pass
     const bool live = kt < kt1;
-    const bool src2 = s_c0 >= p.Cin;
+    const bool ext = s_kh >= p.KH;                      // (scalar) inside the fused 1x1 segment
+    const int cA = ext ? k_cin3 : k_cin;
+    const bool src2 = s_c0 >= cA;
     if (live) {
       if (s_fresh) {
-        const int Cs = src2 ? p.Cin2 : p.Cin;
-        const int dh = s_kh * p.dh, dw = s_kw * p.dw;
+        if (ext) {
+          const int Cs = src2 ? k_cin4 : k_cin3;
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-          int ih = a_ih0[ps] + dh, iw = a_iw0[ps] + dw;
-          bool ok = (unsigned)ih < (unsigned)IHv && (unsigned)iw < (unsigned)IWv;
-          if (p.dilate == 2) {
-            ok = ih >= 0 && iw >= 0 && !((ih | iw) & 1) && (ih >> 1) < p.IH && (iw >> 1) < p.IW;
-            ih >>= 1;
-            iw >>= 1;
-          } else if (p.UH > 0) {
-            if (p.UH == 2 * p.IH) ih >>= 1; else ih = (ih * p.IH) / p.UH;
-            if (p.UW == 2 * p.IW) iw >>= 1; else iw = (iw * p.IW) / p.UW;
+          for (int ps = 0; ps < A_PASSES; ++ps) cur_off[ps] = (unsigned)a_m[ps] * (unsigned)(Cs * 2) + kchunk * 16;
+        } else {
+          const int Cs = src2 ? k_cin2 : k_cin;
+          const int dh = s_kh * p.dh, dw = s_kw * p.dw;
+#pragma unroll
+          for (int ps = 0; ps < A_PASSES; ++ps) {
+            int ih = a_ih0[ps] + dh, iw = a_iw0[ps] + dw;
+            bool ok = (unsigned)ih < (unsigned)IHv && (unsigned)iw < (unsigned)IWv;
+            if (p.dilate == 2) {
+              ok = ih >= 0 && iw >= 0 && !((ih | iw) & 1) && (ih >> 1) < p.IH && (iw >> 1) < p.IW;
+              ih >>= 1;
+              iw >>= 1;
+            } else if (p.UH > 0) {
+              if (p.UH == 2 * p.IH) ih >>= 1; else ih = (ih * p.IH) / p.UH;
+              if (p.UW == 2 * p.IW) iw >>= 1; else iw = (iw * p.IW) / p.UW;
+            }
+            const unsigned off = (unsigned)(a_pix0[ps] + ih * p.IW + iw) * (unsigned)(Cs * 2) + kchunk * 16;
+            cur_off[ps] = ok ? off : OOB;
           }
-          const unsigned off = (unsigned)(a_pix0[ps] + ih * p.IW + iw) * (unsigned)(Cs * 2) + kchunk * 16;
-          cur_off[ps] = ok ? off : OOB;
         }
         s_fresh = false;
       }
-      a_soff = (s_c0 - (src2 ? p.Cin : 0)) * 2;
+      a_soff = (s_c0 - (src2 ? cA : 0)) * 2;
       b_soff = kt * BK * 2;
     }
-    if (src2) {
+    if (ext) {   // descriptors built on the spot (4 SGPRs, transient): the kernel already sits at the SGPR budget
+      if (src2) {
+        const __amdgpu_buffer_rsrc_t rs_x4 = make_rsrc(p.x4, p.x4_bytes);
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x4, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, cur_off[ps], a_soff, 0, 0);
+      } else {
+        const __amdgpu_buffer_rsrc_t rs_x3 = make_rsrc(p.x3, p.x3_bytes);
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x3, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, cur_off[ps], a_soff, 0, 0);
+      }
+    } else if (src2) {
 #pragma unroll
       for (int ps = 0; ps < A_PASSES; ++ps)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, cur_off[ps], a_soff, 0, 0);
@@ -915,8 +945,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
     }
     if (live) {   // advance the scalar cursor by one K-tile
       s_c0 += BK;
-      if (s_c0 == p.Cin && p.Cin2 > 0) s_fresh = true;
-      if (s_c0 >= p.Ctot) {
+      if (s_c0 == cA && (ext ? k_cin4 : k_cin2) > 0) s_fresh = true;
+      if (s_c0 >= (ext ? k_c3tot : k_ctot)) {
         s_c0 = 0;
         s_fresh = true;
         if (++s_kw == p.KW) { s_kw = 0; ++s_kh; }
@@ -1238,8 +1268,8 @@ int launch_tile(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   // activation and < 2 GiB activations (32-bit buffer offsets, 0x80000000 = "padded tap").
   const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u &&
                     d.x2_bytes < 0x80000000u;
-  if (!fast && d.ln_s) {
-    aldm_set_error("igemm: the folded LayerNorm needs the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
+  if (!fast && (d.ln_s || d.x3)) {
+    aldm_set_error("igemm: the folded LayerNorm / the fused second-source segment need the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
     return ALDM_E_UNSUPPORTED;
   }
   if (!fast) return launch_rp<BM, BN, WM, WN, 0>(d, Rp, vt, st);

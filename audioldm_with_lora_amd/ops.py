@@ -48,6 +48,7 @@ class PackedW:
     ln_sa: Optional[torch.Tensor] = None       # fp32 [Rp]: row sums of A diag(gamma)
     ln_ca: Optional[torch.Tensor] = None       # fp32 [Rp]: A beta
     ln_eps: float = 1e-5
+    Cext: int = 0                               # channels of the fused 1x1 second-source segment appended to every weight row
 
     @property
     def Kpad(self):
@@ -67,6 +68,18 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedW:
     co, ci, kh, kw = weight.shape
     w = _pad_k(weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci))
     return PackedW(w, None if bias is None else bias.detach().float().contiguous(), co, ci, kh, kw)
+
+
+def pack_conv_shortcut(weight, bias, sc_weight, sc_bias) -> PackedW:
+    """ResnetBlock2D.conv2 [Cout, C, 3, 3] and conv_shortcut [Cout, Cin, 1, 1] as ONE weight matrix [Cout][(kh, kw, c) | cin]:
+    conv2(h) + conv_shortcut(x) is then a single implicit GEMM whose K loop ends with a 1x1 segment over the block input
+    (aldm_igemm x3 / x4).  Needs C % 64 == 0 and Cin % 64 == 0 (the LDS-DMA path); the caller falls back to two launches otherwise."""
+    co, ci, kh, kw = weight.shape
+    w2 = weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    ws = sc_weight.detach().reshape(co, -1)
+    pw = PackedW(_pad_k(torch.cat([w2, ws], dim=1)), (bias.detach().float() + sc_bias.detach().float()).contiguous(), co, ci, kh, kw)
+    pw.Cext = ws.shape[1]
+    return pw
 
 
 def pack_conv1d(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedW:
@@ -389,7 +402,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None):
+         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None, x3=None, x4=None):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
@@ -413,6 +426,9 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         assert x2.dtype == torch.bfloat16 and x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
         C2 = x2.shape[3]
     assert C1 + C2 == pw.Cin, f"conv: input channels {C1}+{C2} != packed {pw.Cin}"
+    C3 = x3.shape[3] if x3 is not None else 0
+    C4 = x4.shape[3] if x4 is not None else 0
+    assert C3 + C4 == pw.Cext, f"conv: fused 1x1 segment channels {C3}+{C4} != packed {pw.Cext}"
     KH, KW = pw.KH, pw.KW
     VH, VW = (up_size if up_size is not None else (IH, IW))
     if out_hw is None:
@@ -431,6 +447,12 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         assert out_pix_stride == 1 and out_pix_offset == 0, "strided output rows need an explicit batch stride"
         out_batch_stride = OH * OW * out_ld
     a = IgemmArgs()
+    if x3 is not None:
+        for t in (x3, x4):
+            assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous() and tuple(t.shape[:3]) == (B, OH, OW))
+        a.x3, a.Cin3 = x3.data_ptr(), C3
+        if x4 is not None:
+            a.x4, a.Cin4 = x4.data_ptr(), C4
     a.x, a.x2 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
     a.B, a.IH, a.IW, a.Cin, a.Cin2 = B, IH, IW, C1, C2
     a.UH, a.UW = (up_size if up_size is not None else (0, 0))
@@ -493,11 +515,12 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if tile == 0 and ring == 0:
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
-        sfx = ("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "") + (" rs" if rowstats else "") + (" lp" if ln_parts is not None else "")
+        sfx = (("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "") + (" rs" if rowstats else "")
+               + (" lp" if ln_parts is not None else "") + (f" e{C3}+{C4}" if x3 is not None else ""))
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
-                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None
+                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None and x3 is None
                           and (up_size is None or up_size == (2 * IH, 2 * IW)))
         cfg = TUNED.get(key)
         if cfg is None and TUNED_LEGACY_KEYS:           # tables written before the geometry suffix existed
@@ -532,9 +555,9 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     lib = _lib.load()
     eff = lib.aldm_igemm_effective_splits(C.byref(a)) if (gn_defer and splits > 1) else 1
     a.defer_reduce = 1 if eff > 1 else 0
-    ktot = KH * KW * pw.Cin
+    ktot = KH * KW * pw.Cin + pw.Cext
     flops = 2.0 * M * pw.N * ktot + (2.0 * M * pw.Rp * (ktot + pw.N) if pw.Rp else 0.0)
-    nbytes = 2.0 * (B * IH * IW * pw.Cin + pw.N * ktot + M * ncols)
+    nbytes = 2.0 * (B * IH * IW * pw.Cin + M * pw.Cext + pw.N * ktot + M * ncols)
     label = (f"igemm_{TILE_NAMES[tile]}_r{pw.Rp}{'_vt' if vt is not None else ''}{'_sk' if splits > 1 else ''}"
              f"|M{M} N{pw.N} K{ktot}{' geglu' if pw.geglu else ''}")
 
@@ -543,7 +566,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         global _PENDING
         if gn is None:
             if eff > 1:
-                _PENDING = Deferred(out, a.workspace, eff, a.bias, a.rowbias, a.rowbias_ld, a.res, (pw, rowbias, res))
+                _PENDING = Deferred(out, a.workspace, eff, a.bias, a.rowbias, a.rowbias_ld, a.res, (pw, rowbias, res, x3, x4))
                 return _PENDING
             return (out, stats) if rowstats else out
         gamma, beta, groups, eps, act = gn

@@ -162,10 +162,14 @@ def _lin(mod):
 
 
 def pack_resnet(r: ResnetBlock2D):
+    sc = r.conv_shortcut if hasattr(r, "conv_shortcut") else None
+    # conv_shortcut(input) + conv2(h) as ONE implicit GEMM (ops.pack_conv_shortcut) wherever the LDS-DMA path can take it
+    fuse = sc is not None and r.cout % 64 == 0 and r.cin % 64 == 0
     return SimpleNamespace(
         g1=_f32(r.norm1.weight), b1=_f32(r.norm1.bias), g2=_f32(r.norm2.weight), b2=_f32(r.norm2.bias),
         conv1=ops.pack_conv(r.conv1.weight, r.conv1.bias), conv2=ops.pack_conv(r.conv2.weight, r.conv2.bias),
-        shortcut=ops.pack_conv(r.conv_shortcut.weight, r.conv_shortcut.bias) if hasattr(r, "conv_shortcut") else None,
+        shortcut=ops.pack_conv(sc.weight, sc.bias) if sc is not None else None,
+        conv2s=ops.pack_conv_shortcut(r.conv2.weight, r.conv2.bias, sc.weight, sc.bias) if fuse else None,
         groups=r.groups, eps=r.eps, cout=r.cout, temb_off=0)
 
 
@@ -246,6 +250,11 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=No
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
     # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
     h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=(P.g2, P.b2, P.groups, P.eps, ACT_SILU))
+    if P.conv2s is not None and (x2 is None or x2.shape[3] % 64 == 0) and x.shape[3] % 64 == 0:
+        # the 1x1 shortcut over the block input (| skip) rides at the end of conv2's K loop: one launch instead of two
+        if next_gn is not None:
+            return ops.conv(h, P.conv2s, pad=(1, 1), x3=x, x4=x2, gn=next_gn, gn_keep=True)
+        return ops.conv(h, P.conv2s, pad=(1, 1), x3=x, x4=x2, defer=(defer or False))
     if P.shortcut is not None:
         xs = ops.conv(x, P.shortcut, x2=x2)
     else:

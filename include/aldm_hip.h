@@ -102,6 +102,12 @@ typedef struct {
      activation tiles in the K loop -- the LayerNorm launch disappears and no GEMM pays for the statistics twice. */
   float* rowstat_out;
   const float* ln_parts;  int ln_nparts;
+  /* A 1x1 convolution over a SECOND pair of sources, accumulated into the same output tile: K grows by Cin3 + Cin4 columns
+     appended to every weight row (w [Cout][KH*KW*(Cin+Cin2) | Cin3+Cin4]).  x3 (| x4) are bf16 [B][OH][OW][Cin3 (Cin4)], i.e.
+     they have the OUTPUT's spatial extent.  This is ResnetBlock2D's `conv_shortcut(input) + conv2(h)` as ONE launch
+     (diffusers resnet.py under [REF script/train/train_audioldm_lora.py:539-546]); LDS-DMA path only (all channel counts
+     multiples of 64, KH*KW*(Cin+Cin2) a multiple of 64), not with the halo tiles. */
+  const void* x3;  const void* x4;  int Cin3, Cin4;
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
