@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the LoRA-training and end-to-end pipeline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--fine", action="store_true", help="print the per-kernel-per-shape table to stderr")
+    ap.add_argument("--no-trace", action="store_true", help="skip the in-process kernel tracer (use under rocprofv3: one tracer at a time)")
     ap.add_argument("--fp8-attention", action="store_true", help="BASELINE config 5: fp8 (e4m3) Q/K/V/P attention operands")
     args = ap.parse_args()
 
@@ -373,7 +374,7 @@ def main():
     rows = kernels = span_us = None
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
-        if eng.graph is not None:
+        if eng.graph is not None and not args.no_trace:
             kernels, span_us = trace_replays(eng)
         ev_rows = launch_rows(eng)
         rows = join_trace(ev_rows, kernels) if kernels else None
