@@ -678,6 +678,21 @@ def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False, prescaled=Fa
     return out
 
 
+WIDE_HEAD_DIMS = (128, 256, 512)
+
+
+def attention_wide(qk, vt, B, N, d, out=None):
+    """Single wide head (AutoencoderKL mid-block): qk [B*N, 2d] (pre-scaled Q | K), vt [B, d, npad] zero beyond N, npad % 32 == 0."""
+    _require_gpu(qk)
+    assert d in WIDE_HEAD_DIMS and vt.shape[2] % 32 == 0 and vt.shape[2] >= N
+    if out is None:
+        out = torch.empty(B * N, d, dtype=torch.bfloat16, device=qk.device)
+    check(_launch(f"attention_wide_d{d}_n{N}", 4.0 * B * N * N * d, 2.0 * 4 * B * N * d, lambda: _lib.load().aldm_attention_wide(
+        C.c_void_p(qk.data_ptr()), qk.shape[1], C.c_void_p(qk.data_ptr() + 2 * d), qk.shape[1], _p(vt), vt.shape[2], vt.stride(0),
+        B, N, d, _p(out), d, _stream())), "aldm_attention_wide")
+    return out
+
+
 def embed_layernorm(ids, word, pos, type0, gamma, beta, eps, pad_idx):
     """ids int64 [B, L] (device) -> LayerNorm(word[ids] + type0 + pos[position_ids]) as bf16 [B*L, C]."""
     _require_gpu(ids)

@@ -101,17 +101,31 @@ class Encoder(nn.Module):
 
 
 def pack_vae_attention(a: VaeAttention):
+    c = a.to_q.weight.shape[0]
+    # fused q | k | v projection for the flash kernel (ops.attention_wide): the softmax scale C^-0.5 (and log2 e) rides in to_q
+    qs = ops.LOG2E / (c ** 0.5)
+    wqkv = torch.cat([a.to_q.weight.detach().float() * qs, a.to_k.weight.detach().float(), a.to_v.weight.detach().float()])
+    bqkv = torch.cat([a.to_q.bias.detach().float() * qs, a.to_k.bias.detach().float(), a.to_v.bias.detach().float()])
     return SimpleNamespace(
         g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias), groups=a.groups,
         q=ops.pack_linear(a.to_q.weight, a.to_q.bias), k=ops.pack_linear(a.to_k.weight, a.to_k.bias),
         v=ops.pack_linear(a.to_v.weight, a.to_v.bias), out=ops.pack_linear(a.to_out[0].weight, a.to_out[0].bias),
-        c=a.to_q.weight.shape[0])
+        qkv=ops.pack_linear(wqkv, bqkv) if c in ops.WIDE_HEAD_DIMS else None, c=c)
 
 
 def run_vae_attention(P, x):
     B, H, W, C = x.shape
     N = H * W
     hn = ops.groupnorm(x, P.g, P.b, P.groups, EPS, ACT_NONE).view(B * N, C)
+    if P.qkv is not None:
+        # diffusers Attention of the VAE mid block (1 head, d = C): ONE fused projection GEMM (Q | K row-major, V^T token-major
+        # straight from the epilogue) -> flash attention over the wide head -> out-projection + residual.  The N x N score
+        # matrix (64 MB fp32 per 10 s clip) never exists.
+        npad = (N + 31) // 32 * 32
+        vt = torch.zeros(B, C, npad, dtype=torch.bfloat16, device=x.device)       # keys beyond N must read as zeros
+        qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad)
+        o = ops.attention_wide(qk.view(B * N, 2 * C), vt, B, N, C)
+        return ops.linear(o, P.out, res=x.view(B * N, C)).view(B, H, W, C)
     q = ops.linear(hn, P.q)
     k = ops.linear(hn, P.k)
     npad = (N + 63) // 64 * 64

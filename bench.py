@@ -111,11 +111,11 @@ def join_trace(rows, kernels):
         if k >= len(kernels):
             print(f"[bench] kernel trace: {len(kernels)} kernels per replay < {len(rows)} launch rows", file=sys.stderr)
             return None
-        us, names = kernels[k][1], [kernels[k][0]]
+        us, names = kernels[k][1], [kernels[k]]
         k += 1
         if k < len(kernels) and "igemm_reduce_kernel" in kernels[k][0] and label.startswith("igemm"):
             us += kernels[k][1]
-            names.append(kernels[k][0])
+            names.append(kernels[k])
             k += 1
         out.append((label, flops, nbytes, ev_us, site, us, names))
     if k != len(kernels):
@@ -124,11 +124,32 @@ def join_trace(rows, kernels):
     return out
 
 
-def aggregate(rows, fine=False):
+def short_symbol(name):
+    """Kernel symbol as rocprofv3's summary prints it: template arguments kept, namespaces / parameter list dropped."""
+    import re
+    name = name.replace("(anonymous namespace)::", "").replace("aldm_igemm_detail::", "").replace("void ", "")
+    m = re.match(r"(\w+<[^>]*>)", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+def aggregate(rows, fine=False, by_symbol=False):
+    """Totals per label family (default), per label (fine) or per kernel SYMBOL (by_symbol: one entry per template instantiation,
+    exactly the rows of a rocprofv3 --stats summary; flops / bytes of a launch go to its first kernel, a split-K reduce kernel
+    is its own entry)."""
     agg = {}
     for label, flops, nbytes, ev_us, site, us, names in rows:
+        if by_symbol:
+            for i, (nm, kus) in enumerate(names):
+                a = agg.setdefault(short_symbol(nm), dict(us=0.0, ev_us=0.0, flops=0.0, bytes=0.0, launches=0, kernel=nm, label=label.split("|")[0]))
+                a["us"] += kus
+                a["launches"] += 1
+                if i == 0:
+                    a["ev_us"] += ev_us
+                    a["flops"] += flops
+                    a["bytes"] += nbytes
+            continue
         key = label if fine else label.split("|")[0]
-        a = agg.setdefault(key, dict(us=0.0, ev_us=0.0, flops=0.0, bytes=0.0, launches=0, kernel=names[0]))
+        a = agg.setdefault(key, dict(us=0.0, ev_us=0.0, flops=0.0, bytes=0.0, launches=0, kernel=names[0][0]))
         a["us"] += us
         a["ev_us"] += ev_us
         a["flops"] += flops
@@ -177,10 +198,9 @@ def traffic_from_profile(kernel_name):
     if not files:
         return None, None
     prof = json.load(open(files[-1]))
-    short = kernel_name.replace("void ", "").replace("aldm_igemm_detail::", "").split("(")[0]
-    for k, v in prof.items():
-        if k == short or k.endswith(short) or short.endswith(k):
-            return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    short = short_symbol(kernel_name)
+    if short in prof:
+        return prof[short]["hbm_bytes_per_launch"], os.path.basename(files[-1])
     return None, os.path.basename(files[-1])
 
 
@@ -381,7 +401,7 @@ def main():
         source = "trace"
         if rows is None:                                     # tracer missing or the sequence did not line up: events only
             source = "events"
-            rows = [(l, f, b, e, s, e, ["?"]) for l, f, b, e, s in ev_rows]
+            rows = [(l, f, b, e, s, e, [(l.split("|")[0], e)]) for l, f, b, e, s in ev_rows]
             print("[bench] per-kernel durations fall back to hipEvent pairs", file=sys.stderr)
 
     pipe_t = None
@@ -398,8 +418,11 @@ def main():
             train16 = bench_train(world, rank, steps=4, warmup=3, rank_lora=16)
     if rank == 0:
         agg = aggregate(rows)
-        dom_label, dom = max(agg.items(), key=lambda kv: kv[1]["us"])
         total_us = sum(v["us"] for v in agg.values())
+        # the dominant kernel = the SYMBOL (template instantiation) with the largest share of the step -- one row of the rocprofv3
+        # summary in profiles/, so `frac` can be recomputed from that file: achieved = flops per launch / its average duration
+        sym = aggregate(rows, by_symbol=True)
+        dom_label, dom = max(((k, v) for k, v in sym.items() if v["flops"] > 0), key=lambda kv: kv[1]["us"])
         if args.fine:
             for k, v in sorted(aggregate(rows, fine=True).items(), key=lambda kv: -kv[1]["us"]):
                 print(f"{k:64s} {v['launches']:3d}x {v['us'] / v['launches']:7.1f} us (events {v['ev_us'] / v['launches']:7.1f})  "
@@ -416,7 +439,7 @@ def main():
                     "traffic_unit": "HBM bytes/launch (PMC, profiles/%s)" % traffic_src if traffic else None,
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
-                    "kernel": dom_label, "kernel_symbol": dom["kernel"][:96], "launches_per_step": dom["launches"],
+                    "kernel": dom_label, "kernel_family": dom.get("label"), "launches_per_step": dom["launches"],
                     "avg_launch_us": round(dom["us"] / dom["launches"], 2),
                     "avg_launch_us_events": round(dom["ev_us"] / dom["launches"], 2),
                     "duration_source": ("device timestamps of the replayed graph's kernels (roctracer; = rocprofv3 --kernel-trace)"

@@ -168,6 +168,13 @@ int aldm_attention(const void* q, int ldq, const void* k, int ldk, const void* v
 int aldm_attention_prescaled(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                              long long vt_batch_stride, int B, int N, int H, int d, void* out, int out_ld, void* stream);
 
+/* Single-head attention with a WIDE head (d = 128 / 256 / 512): AutoencoderKL's mid-block attention (1 head x 512 over
+   N = H*W = 2000..4096 tokens) inside vae.encode / vae.decode [REF script/train/train_audioldm_lora.py:370,495-496],
+   [REF script/inference/generate_audio.py:47-52].  Flash-style (no N x N score matrix); q pre-scaled as for
+   aldm_attention_prescaled; q, k bf16 rows [B*N][ld*]; vt [B][d][vt_ld] token-contiguous, vt_ld % 32 == 0 and ZERO beyond N. */
+int aldm_attention_wide(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_batch_stride,
+                        int B, int N, int d, void* out, int out_ld, void* stream);
+
 /* Same, additionally writing the log2-domain log-sum-exp of the scaled scores, lse [B][H][N] fp32 (training). */
 /* Same core with a per-batch-item key count kv_len[B] (int32, device): keys >= kv_len[b] are excluded exactly as an
    additive -inf attention_mask excludes right-padded tokens, and the key loop stops at the last valid tile.  Query

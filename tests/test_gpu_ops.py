@@ -334,6 +334,43 @@ def test_attention_online_softmax_rescale_branch(ops):
     close(ops.attention(qk, vt, B, N, H, d), want, rtol=2e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_prescaled_path_and_deferred_rescale(ops, prescaled):
+    """The UNet's path hands the kernel a Q that already carries d^-0.5 log2(e); a spike at a late key tile (more than
+    RESCALE_THR above the running max) must take the deferred-rescale branch, small increases must not change the result."""
+    g = torch.Generator().manual_seed(12)
+    B, N, H, d = 2, 1000, 8, 32
+    Cc = H * d
+    q, k, v = (bf(torch.randn(B, N, Cc, generator=g)) for _ in range(3))
+    k[0, 900] = bf(q[0, 7] * 6.0)
+    k[1, 130] = bf(q[1, 999] * 3.0)
+    sp = lambda z: z.view(B, N, H, d).transpose(1, 2)
+    want = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B * N, Cc)
+    qs = (q * (ops.LOG2E / math.sqrt(d))) if prescaled else q
+    qk = torch.cat([qs, k], -1).view(B * N, 2 * Cc).to(torch.bfloat16).to(DEV)
+    vt = v.transpose(1, 2).contiguous().to(torch.bfloat16).to(DEV)
+    close(ops.attention(qk, vt, B, N, H, d, prescaled=prescaled), want, rtol=3e-2, atol=1.5e-2)
+
+
+@pytest.mark.parametrize("B,N,d", [(2, 200, 128), (1, 1000, 256), (2, 2048, 512), (1, 4000, 512), (1, 37, 512)])
+def test_attention_wide_head(ops, B, N, d):
+    """AutoencoderKL mid-block attention: 1 head, d = C, flash-style on 16x16x32 MFMA tiles (aldm_attention_wide), ragged N,
+    keys zero-padded to a multiple of 32, plus a forced late rescale."""
+    g = torch.Generator().manual_seed(13)
+    q, k, v = (bf(torch.randn(B, N, d, generator=g)) for _ in range(3))
+    q = bf(q * 2.0)
+    if N > 100:
+        k[0, N - 10] = bf(q[0, 3] * 1.5)                 # a key far down the sequence dominates query 3
+    want = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0].reshape(B * N, d)
+    qs = q * (ops.LOG2E / math.sqrt(d))
+    qk = torch.cat([qs, k], -1).view(B * N, 2 * d).to(torch.bfloat16).to(DEV)
+    npad = (N + 31) // 32 * 32
+    vt = torch.zeros(B, d, npad, dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :N] = v.transpose(1, 2).to(torch.bfloat16).to(DEV)
+    out = ops.attention_wide(qk, vt, B, N, d)
+    close(out, want, rtol=3e-2, atol=1.5e-2)
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])
