@@ -47,6 +47,7 @@ class IgemmArgs(C.Structure):
         ("defer_reduce", C.c_int),
         ("rowstat_out", C.c_void_p), ("ln_parts", C.c_void_p), ("ln_nparts", C.c_int),
         ("x3", C.c_void_p), ("x4", C.c_void_p), ("Cin3", C.c_int), ("Cin4", C.c_int),
+        ("vt_dual", C.c_int),
     ]
 
 

@@ -25,32 +25,64 @@ struct BwdCfg {
   static constexpr int TBYTES = DT * 32 * VS;     // one token-major tile
 };
 
-// cooperative tile loaders ---------------------------------------------------------------------
+// cooperative tile loaders, split in two so that a tile's global loads fly under the PREVIOUS tile's MFMAs: fetch_* issues
+// every load of the next tile into registers before the compute phase, store_* writes them to LDS after it (behind the barrier
+// that ends the compute phase).  Without the split every key / query tile exposed a full L2 / HBM round trip, in all waves at
+// once: 16 such round trips per workgroup at N = 1024.
 template <int DP, int T>
-__device__ __forceinline__ void load_rows(char* dst, const bf16* base, int ld, int t0, int N, int D, int tid) {
-  constexpr int KS = BwdCfg<DP>::KS;
-  constexpr int CH = TS * (DP / 8);
-  for (int c = tid; c < CH; c += T) {
+struct RowRegs { static constexpr int CH = TS * (DP / 8), NR = (CH + T - 1) / T; bf16x8 v[NR]; };
+template <int DP, int T>
+struct TokRegs { static constexpr int CH = BwdCfg<DP>::DT * 32 * (TS / 8), NR = (CH + T - 1) / T; bf16x8 v[NR]; };
+
+template <int DP, int T>
+__device__ __forceinline__ void fetch_rows(RowRegs<DP, T>& rg, const bf16* base, int ld, int t0, int N, int D, int tid) {
+  using R = RowRegs<DP, T>;
+#pragma unroll
+  for (int i = 0; i < R::NR; ++i) {
+    const int c = tid + i * T;
     const int row = c / (DP / 8), ch = c - row * (DP / 8);
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (t0 + row < N && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(base + (long long)(t0 + row) * ld + ch * 8);
-    *reinterpret_cast<bf16x8*>(dst + row * KS + ch * 16) = v;
+    if (c < R::CH && t0 + row < N && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(base + (long long)(t0 + row) * ld + ch * 8);
+    rg.v[i] = v;
   }
 }
 template <int DP, int T>
-__device__ __forceinline__ void load_tokmajor(char* dst, const bf16* base, int ldt, int t0, int N, int D, int tid) {
-  constexpr int DT = BwdCfg<DP>::DT;
-  constexpr int CH = DT * 32 * (TS / 8);
-  for (int c = tid; c < CH; c += T) {
+__device__ __forceinline__ void store_rows(char* dst, const RowRegs<DP, T>& rg, int tid) {
+  using R = RowRegs<DP, T>;
+  constexpr int KS = BwdCfg<DP>::KS;
+#pragma unroll
+  for (int i = 0; i < R::NR; ++i) {
+    const int c = tid + i * T;
+    const int row = c / (DP / 8), ch = c - row * (DP / 8);
+    if (c < R::CH) *reinterpret_cast<bf16x8*>(dst + row * KS + ch * 16) = rg.v[i];
+  }
+}
+template <int DP, int T>
+__device__ __forceinline__ void fetch_tokmajor(TokRegs<DP, T>& rg, const bf16* base, int ldt, int t0, int N, int D, int tid) {
+  using R = TokRegs<DP, T>;
+#pragma unroll
+  for (int i = 0; i < R::NR; ++i) {
+    const int c = tid + i * T;
     const int row = c >> 3, ch = c & 7;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     const int tb = t0 + ch * 8;
-    if (row < D && tb < N) {
-      v = *reinterpret_cast<const bf16x8*>(base + (long long)row * ldt + tb);
-      if (tb + 8 > N) {
+    if (c < R::CH && row < D && tb < N) v = *reinterpret_cast<const bf16x8*>(base + (long long)row * ldt + tb);
+    rg.v[i] = v;
+  }
+}
+template <int DP, int T>
+__device__ __forceinline__ void store_tokmajor(char* dst, TokRegs<DP, T>& rg, int t0, int N, int tid) {
+  using R = TokRegs<DP, T>;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (tb + j >= N) v[j] = (bf16)0.f;
-      }
+  for (int i = 0; i < R::NR; ++i) {
+    const int c = tid + i * T;
+    const int row = c >> 3, ch = c & 7;
+    if (c >= R::CH) continue;
+    bf16x8 v = rg.v[i];
+    const int tb = t0 + ch * 8;
+    if (tb + 8 > N) {                                   // tail tile: tokens past N must read as zeros
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (tb + j >= N) v[j] = (bf16)0.f;
     }
     uint2* d2 = reinterpret_cast<uint2*>(dst + row * VS + ch * 16);
     const uint4 u = __builtin_bit_cast(uint4, v);
@@ -139,13 +171,23 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   const int ntiles = (N + TS - 1) / TS;
+  RowRegs<DP, T> rk, rv;
+  TokRegs<DP, T> rkt;
+  fetch_rows<DP, T>(rk, kb, ld, 0, N, D, tid);
+  fetch_rows<DP, T>(rv, vb, ld, 0, N, D, tid);
+  fetch_tokmajor<DP, T>(rkt, ktb, ldt, 0, N, D, tid);
   for (int it = 0; it < ntiles; ++it) {
     const int kv0 = it * TS;
+    __syncthreads();                                    // every wave is done with the previous tile's LDS images
+    store_rows<DP, T>(Ks, rk, tid);
+    store_rows<DP, T>(Vs, rv, tid);
+    store_tokmajor<DP, T>(KTs, rkt, kv0, N, tid);
     __syncthreads();
-    load_rows<DP, T>(Ks, kb, ld, kv0, N, D, tid);
-    load_rows<DP, T>(Vs, vb, ld, kv0, N, D, tid);
-    load_tokmajor<DP, T>(KTs, ktb, ldt, kv0, N, D, tid);
-    __syncthreads();
+    if (it + 1 < ntiles) {                              // next tile: loads in flight under this tile's MFMAs
+      fetch_rows<DP, T>(rk, kb, ld, kv0 + TS, N, D, tid);
+      fetch_rows<DP, T>(rv, vb, ld, kv0 + TS, N, D, tid);
+      fetch_tokmajor<DP, T>(rkt, ktb, ldt, kv0 + TS, N, D, tid);
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -240,18 +282,30 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const bf16* __res
     for (int i = 0; i < 16; ++i) { accv[t][i] = 0.f; acck[t][i] = 0.f; }
 
   const int ntiles = (N + TS - 1) / TS;
+  RowRegs<DP, T> rq, rdo;
+  TokRegs<DP, T> rqt, rdot;
+  float rl = 0.f, rd = 0.f;                             // lse / delta of query tid of the tile (threads < TS)
+  auto fetch_tile = [&](int qt0) {
+    fetch_rows<DP, T>(rq, qb, ld, qt0, N, D, tid);
+    fetch_rows<DP, T>(rdo, dob, ldo, qt0, N, D, tid);
+    fetch_tokmajor<DP, T>(rqt, qtb, ldt, qt0, N, D, tid);
+    fetch_tokmajor<DP, T>(rdot, dotb, ldt, qt0, N, D, tid);
+    if (tid < TS) {
+      rl = qt0 + tid < N ? lb[qt0 + tid] : 0.f;
+      rd = qt0 + tid < N ? db[qt0 + tid] : 0.f;
+    }
+  };
+  fetch_tile(0);
   for (int it = 0; it < ntiles; ++it) {
     const int qt0 = it * TS;
+    __syncthreads();                                    // every wave is done with the previous tile's LDS images
+    store_rows<DP, T>(Qs, rq, tid);
+    store_rows<DP, T>(dOs, rdo, tid);
+    store_tokmajor<DP, T>(QTs, rqt, qt0, N, tid);
+    store_tokmajor<DP, T>(dOTs, rdot, qt0, N, tid);
+    if (tid < TS) { Ls[tid] = rl; Ds[tid] = rd; }
     __syncthreads();
-    load_rows<DP, T>(Qs, qb, ld, qt0, N, D, tid);
-    load_rows<DP, T>(dOs, dob, ldo, qt0, N, D, tid);
-    load_tokmajor<DP, T>(QTs, qtb, ldt, qt0, N, D, tid);
-    load_tokmajor<DP, T>(dOTs, dotb, ldt, qt0, N, D, tid);
-    for (int i = tid; i < TS; i += T) {
-      Ls[i] = qt0 + i < N ? lb[qt0 + i] : 0.f;
-      Ds[i] = qt0 + i < N ? db[qt0 + i] : 0.f;
-    }
-    __syncthreads();
+    if (it + 1 < ntiles) fetch_tile(qt0 + TS);          // next tile: loads in flight under this tile's MFMAs
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;

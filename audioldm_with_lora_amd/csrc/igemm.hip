@@ -50,6 +50,9 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
                             p->in_dilate == 0 && p->Rp == 0),
                  "igemm: the fused 1x1 second-source segment (x3 | x4) needs the plain LDS-DMA path: every channel count and KH*KW*(Cin+Cin2) a multiple of 64");
   ALDM_CHECK_ARG(p->x3 || !p->x4, "igemm: x4 without x3");
+  ALDM_CHECK_ARG(!p->vt_dual || (p->vt && !p->res && !p->res2 && !p->out2 && p->out_act == ALDM_ACT_NONE && p->post_act == ALDM_ACT_NONE &&
+                                 p->alpha == 1.f && !p->rowbias && p->out_dtype == ALDM_OUT_BF16),
+                 "igemm: vt_dual needs vt and the plain bf16 epilogue (bias only)");
   ALDM_CHECK_ARG(p->Rp == 0 || p->Rp == 32 || p->Rp == 64, "igemm: Rp must be 0/32/64");
   ALDM_CHECK_ARG(p->Rp == 0 || (p->lora_a && p->lora_b), "igemm: Rp without lora_a/lora_b");
   ALDM_CHECK_ARG(!p->geglu || (p->Cout % 32 == 0 && !p->rowbias), "igemm: GEGLU needs Cout %% 32 == 0");
@@ -86,7 +89,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   d.post_act = p->post_act; d.post_slope = p->post_slope; d.out2 = (bf16*)p->out2;
   d.out_f32 = p->out_dtype == ALDM_OUT_F32; d.out_ld = p->out_ld;
   d.out_bs = p->out_batch_stride; d.out_ps = p->out_pix_stride > 0 ? p->out_pix_stride : 1; d.out_po = p->out_pix_offset;
-  d.vt_col0 = p->vt_col0; d.vt_ld = p->vt_ld; d.vt_bs = p->vt_batch_stride;
+  d.vt_col0 = p->vt_col0; d.vt_ld = p->vt_ld; d.vt_bs = p->vt_batch_stride; d.vt_dual = p->vt ? p->vt_dual : 0;
   d.x3 = (const bf16*)p->x3; d.x4 = (const bf16*)p->x4; d.Cin3 = p->x3 ? p->Cin3 : 0; d.Cin4 = (p->x3 && p->x4) ? p->Cin4 : 0;
   d.C3tot = d.Cin3 + d.Cin4;
   d.nkt = cdiv(Ktot, BK) + d.C3tot / BK;

@@ -53,7 +53,7 @@ struct IgemmDev {
   int rowbias_ld, geglu, out_act; float out_slope; float alpha;
   int post_act; float post_slope; bf16* out2;
   int out_f32, out_ld; long long out_bs; int out_ps, out_po;
-  int vt_col0, vt_ld; long long vt_bs;
+  int vt_col0, vt_ld; long long vt_bs; int vt_dual;
   int splits, kt_per_split, nkt;
   int tiles_n;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
@@ -246,7 +246,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITERS = BM / RSTEP, CH = ITERS < 4 ? ITERS : 4;
   static_assert(NT % GPR == 0 && BM % RSTEP == 0 && ITERS % CH == 0, "epilogue row walk");
   const int r0 = tid / GPR, c = (tid % GPR) * 8, n = n0 + c;
-  const bool std_path = !GLEAN && !SLEAN && !(VT && vt_wg) && (LEAN || (p.splits <= 1 && !p.geglu));
+  const bool dual = VT && vt_wg && p.vt_dual;               // V^T tile that is ALSO stored row-major (trainer's q | k | v)
+  const bool std_path = !GLEAN && !SLEAN && (!(VT && vt_wg) || dual) && (LEAN || (p.splits <= 1 && !p.geglu));
   const bool vec = (n + 7 < p.N) && ((p.out_ld & 7) == 0) && ((p.out_bs & 7) == 0);
   const bool rbvec = vec && ((p.rowbias_ld & 3) == 0);
   float colb[8], lns[8];
@@ -300,10 +301,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     for (int u = 0; u < CH; ++u) {
       if (!ok[u]) continue;
       const int r = r0 + (it0 + u) * RSTEP;
-      const float* src = Cs + r * E::LD + c;
       float v[8];
+      if (VT && vt_wg) {                                     // dual store: the LDS image is transposed ([channel][pixel])
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = src[q];
+        for (int q = 0; q < 8; ++q) v[q] = Cs[(c + q) * E::LDT + r];
+      } else {
+        const float* src = Cs + r * E::LD + c;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[q];
+      }
       if (lnst) {
         const float mu = lnst[r], rs = lnst[BM + r];
 #pragma unroll
@@ -445,7 +451,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         }
       }
     }
-    return;
+    if (!dual) return;
   }
   if constexpr (!LEAN) {
   if (!GLEAN && (SLEAN || p.splits > 1)) {

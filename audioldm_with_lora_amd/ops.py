@@ -402,7 +402,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          up_size=None, in_dilate=0, out_hw=None, in_act=ACT_NONE, in_slope=0.0, rowbias=None, rowbias_ld=0, out_act=ACT_NONE,
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
-         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None, x3=None, x4=None):
+         splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None, x3=None, x4=None,
+         vt_dual=False):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
@@ -437,7 +438,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     else:
         OH, OW = out_hw
     ncols = pw.N // 2 if pw.geglu else pw.N
-    if vt is not None:
+    if vt is not None and not vt_dual:
         ncols = vt_col0
     if out_ld is None:
         out_ld = ncols
@@ -498,6 +499,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     a.out_pix_stride, a.out_pix_offset = out_pix_stride, out_pix_offset
     if vt is not None:
         a.vt, a.vt_col0, a.vt_ld, a.vt_batch_stride = vt.data_ptr(), vt_col0, vt_ld, vt_batch_stride
+        a.vt_dual = 1 if vt_dual else 0
     M = B * OH * OW
     ktiles = pw.Kpad // BK
     can_split = not (vt is not None or pw.N % 4 or pw.ln_s is not None)
@@ -516,7 +518,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
         sfx = (("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "") + (" rs" if rowstats else "")
-               + (" lp" if ln_parts is not None else "") + (f" e{C3}+{C4}" if x3 is not None else ""))
+               + (" lp" if ln_parts is not None else "") + (f" e{C3}+{C4}" if x3 is not None else "") + (" vd" if vt_dual else ""))
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
@@ -812,11 +814,13 @@ def attention_train(qkv, qkvT, B, N, H, d):
     return out, lse
 
 
-def attention_bwd(qkv, qkvT, dO, O, lse, B, N, H, d):
-    """-> dqkv [B*N, 3C] (dQ | dK | dV)."""
+def attention_bwd(qkv, qkvT, dO, O, lse, B, N, H, d, dOT=None):
+    """-> dqkv [B*N, 3C] (dQ | dK | dV).  dOT: dO token-major [B, C, Npad] when its producer already stored it that way."""
     Cc = H * d
     npad = qkvT.shape[2]
-    dOT = transpose_tokens(dO, B, N, Cc, npad)
+    if dOT is None:
+        dOT = transpose_tokens(dO, B, N, Cc, npad)
+    assert tuple(dOT.shape) == (B, Cc, npad)
     dqkv = torch.empty(B * N, 3 * Cc, dtype=torch.bfloat16, device=qkv.device)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     base, tb, gb = qkv.data_ptr(), qkvT.data_ptr(), dqkv.data_ptr()

@@ -35,10 +35,11 @@ BK = 64
 # tape
 # ----------------------------------------------------------------------------------------------
 class Var:
-    __slots__ = ("t", "g", "rg", "gn")
+    __slots__ = ("t", "g", "rg", "gn", "tT", "want_T", "gT")
 
     def __init__(self, t, rg=False):
         self.t, self.g, self.rg = t, None, rg
+        self.tT = self.want_T = self.gT = None                       # token-major copies (see t_lora_linear)
         self.gn = None               # (channels, groups) when this is a GroupNorm output: its single consumer conv may hand the
                                      # norm's backward its dX as split-K partial tiles (g is then an ops.Deferred)
 
@@ -215,11 +216,28 @@ class LoraSite:
         self.rows_db, self.rows_da = pack(rows_db), pack(rows_da)
 
 
-def t_lora_linear(tape, x, site, res=None):
-    """x [M, K] -> y [M, N] with the LoRA side channel; records dX + dA/dB."""
+def _tok_major_buf(B, N, Cc, dev):
+    npad = (N + 7) // 8 * 8
+    mk = torch.empty if npad == N else torch.zeros            # the GEMM writes tokens < N only: keep the padding zero
+    return mk(B, Cc, npad, dtype=torch.bfloat16, device=dev)
+
+
+def t_lora_linear(tape, x, site, res=None, tok=None):
+    """x [M, K] -> y [M, N] with the LoRA side channel; records dX + dA/dB.
+    tok = (B, N): the GEMM ALSO stores y token-major ([B, N_out, Npad], aldm_igemm vt_dual) -- returned as y.tT; the flash
+    kernels read q | k | v that way, so the separate transpose launch disappears.  A Var x with x.want_T = (B, N) asks the same
+    of its GRADIENT (the attention backward reads dO token-major): the dX launch then leaves it in x.gT."""
     M = x.t.shape[0]
     T = torch.empty(M, site.Rp, dtype=torch.bfloat16, device=x.t.device)
-    y = Var(ops.linear(x.t, site.fwd, res=(res.t if res is not None else None), lora_t_out=T, splits=1), True)
+    if tok is not None and res is None:
+        Bq, Nq = tok
+        yT = _tok_major_buf(Bq, Nq, site.N, x.t.device)
+        out = ops.conv(x.t.view(Bq, 1, Nq, site.K), site.fwd, lora_t_out=T, splits=1, vt=yT, vt_col0=0, vt_ld=yT.shape[2],
+                       vt_batch_stride=site.N * yT.shape[2], vt_dual=True).view(M, site.N)
+        y = Var(out, True)
+        y.tT = yT
+    else:
+        y = Var(ops.linear(x.t, site.fwd, res=(res.t if res is not None else None), lora_t_out=T, splits=1), True)
 
     def bwd():
         dy = y.g
@@ -228,7 +246,15 @@ def t_lora_linear(tape, x, site, res=None):
         acc(res, dy)
         U = torch.empty(M, site.Rp, dtype=torch.bfloat16, device=dy.device)
         g0 = prior(x, x.t)
-        put(x, ops.linear(dy, site.bwd, lora_t_out=U, splits=1, res=g0))     # dx = dy W + (dy sB) A (+ prior) ; U = dy sB
+        want = getattr(x, "want_T", None)
+        if want is not None and g0 is None:                                  # dx row-major AND token-major from one launch
+            Bq, Nq = want
+            gT = _tok_major_buf(Bq, Nq, site.K, dy.device)
+            put(x, ops.conv(dy.view(Bq, 1, Nq, site.N), site.bwd, lora_t_out=U, splits=1, vt=gT, vt_col0=0, vt_ld=gT.shape[2],
+                            vt_batch_stride=site.K * gT.shape[2], vt_dual=True).view(M, site.K))
+            x.gT = gT
+        else:
+            put(x, ops.linear(dy, site.bwd, lora_t_out=U, splits=1, res=g0)) # dx = dy W + (dy sB) A (+ prior) ; U = dy sB
         if tape.tn is not None:
             tape.tn.add(T, dy, site.rows_db, site.N)
             tape.tn.add(U, x.t, site.rows_da, site.K)
@@ -390,7 +416,7 @@ class LoraTrainer:
         qkv_site, out_site = self.sites[id(tblk_attn)]
         C, H, d = Pa.c, Pa.heads, Pa.d
         if qkv_site is not None:
-            qkv = t_lora_linear(tape, hn, qkv_site)
+            qkv = t_lora_linear(tape, hn, qkv_site, tok=(B, N))
         else:
             if "qkv_plain" not in Pa.__dict__:
                 wq, wk, wv = _base(tblk_attn.to_q), _base(tblk_attn.to_k), _base(tblk_attn.to_v)
@@ -398,13 +424,14 @@ class LoraTrainer:
                 Pa.qkv_plain = ops.pack_linear(torch.cat([wq.weight, wk.weight, wv.weight]), bias)
             qkv = t_conv(tape, t_view(tape, hn, (1, 1, B * N, C)), Pa.qkv_plain)
             qkv = t_view(tape, qkv, (B * N, 3 * C))
-        qkvT = ops.transpose_tokens(qkv.t, B, N, 3 * C)
+        qkvT = qkv.tT if qkv.tT is not None else ops.transpose_tokens(qkv.t, B, N, 3 * C)
         o_t, lse = ops.attention_train(qkv.t, qkvT, B, N, H, d)
         o = Var(o_t, True)
+        o.want_T = (B, N)                                   # the out-projection's dX launch leaves dO token-major in o.gT
 
         def bwd():
             if o.g is not None:
-                acc(qkv, ops.attention_bwd(qkv.t, qkvT, o.g, o.t, lse, B, N, H, d))
+                acc(qkv, ops.attention_bwd(qkv.t, qkvT, o.g, o.t, lse, B, N, H, d, dOT=o.gT))
         if qkv.rg:
             tape.record(bwd)
         o.rg = qkv.rg

@@ -108,6 +108,10 @@ typedef struct {
      (diffusers resnet.py under [REF script/train/train_audioldm_lora.py:539-546]); LDS-DMA path only (all channel counts
      multiples of 64, KH*KW*(Cin+Cin2) a multiple of 64), not with the halo tiles. */
   const void* x3;  const void* x4;  int Cin3, Cin4;
+  /* with vt: the transposed columns are ALSO stored row-major in `out` (out_ld counts every column then).  The LoRA trainer's
+     fused QKV GEMM needs q | k | v row-major (backward operands) and token-major (flash kernels' operands): one launch instead
+     of a GEMM plus a transpose.  Standard epilogue only: no residual / activation / out2 on such a launch. */
+  int vt_dual;
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
