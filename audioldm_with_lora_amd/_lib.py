@@ -46,6 +46,7 @@ class IgemmArgs(C.Structure):
         ("ring", C.c_int),
         ("defer_reduce", C.c_int),
         ("rowstat_out", C.c_void_p), ("ln_parts", C.c_void_p), ("ln_nparts", C.c_int),
+        ("qstat_out", C.c_void_p),
         ("x3", C.c_void_p), ("x4", C.c_void_p), ("Cin3", C.c_int), ("Cin4", C.c_int),
         ("vt_dual", C.c_int),
     ]
@@ -63,6 +64,9 @@ PROTOTYPES = {
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                  C.c_void_p]),
     "aldm_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,

@@ -70,6 +70,9 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
                  "igemm: folded LayerNorm needs a 1x1 single-source GEMM without split-K (and ln_sa/ln_ca with LoRA)");
   ALDM_CHECK_ARG(!p->rowstat_out || (!p->vt && p->splits <= 1 && !p->geglu && p->out_dtype == ALDM_OUT_BF16 && p->Cout % 64 == 0 && !p->out2),
                  "igemm: rowstat_out needs the standard bf16 epilogue (no V^T / split-K / GEGLU / out2) and Cout %% 64 == 0");
+  ALDM_CHECK_ARG(!p->qstat_out || (!p->vt && p->splits <= 1 && !p->geglu && p->out_dtype == ALDM_OUT_BF16 && p->Cout % 8 == 0 &&
+                                   p->out_pix_stride <= 1 && p->Rp == 0 && !p->ln_s && !p->rowstat_out),
+                 "igemm: qstat_out needs the standard bf16 epilogue (no V^T / split-K / GEGLU / LoRA / LayerNorm hand-over) and Cout %% 8 == 0");
   ALDM_CHECK_ARG(!p->ln_parts || (p->ln_s && p->ln_nparts > 0 && p->ln_nparts <= 64), "igemm: ln_parts needs ln_s and 1..64 partials per row");
   ALDM_CHECK_ARG(p->ring == 0 || (p->ring >= 2 && p->ring <= 4), "igemm: ring must be 0 (auto) or 2..4");
   ALDM_CHECK_ARG(p->in_dilate == 0 || (p->in_dilate == 2 && p->UH == 0), "igemm: in_dilate must be 0 or 2 (and excludes UH/UW)");
@@ -113,6 +116,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.fd_ohw = make_fastdiv((unsigned)d.OHW); d.fd_ow = make_fastdiv((unsigned)d.OW); d.fd_halo = make_fastdiv((unsigned)d.OW + 2u);
     d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
     d.rowstat = p->rowstat_out; d.ln_parts = p->ln_parts; d.ln_np = p->ln_nparts;
+    d.qstat = p->qstat_out; d.qtile = -1;
 #ifdef ALDM_DIAG
     d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer
 #else
@@ -132,6 +136,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_HALO_128x128:
     case ALDM_TILE_HALO_64x128:
+      // (qstat_out is fine with the halo tiles: they are image-aligned, slot 0)
       if (p->Rp || vt || p->rowstat_out || p->x3) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics / second-source segment"); return ALDM_E_UNSUPPORTED; }
       rc = aldm_launch_halo(d, tile, p->ring, st);
       break;

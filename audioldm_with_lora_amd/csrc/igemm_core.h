@@ -61,6 +61,7 @@ struct IgemmDev {
   FastDiv fd_ohw, fd_ow, fd_halo;   // fd_halo: / (OW + 2), halo kernel only
   const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;   // LayerNorm folded into the GEMM (see below)
   const bf16* x3; const bf16* x4; int Cin3, Cin4, C3tot; unsigned x3_bytes, x4_bytes;   // fused 1x1 second-source segment (shortcut)
+  float* qstat; int qtile;    // GroupNorm hand-over: per (M-tile, image slot, 4-channel quad) partial (sum, sum of squares); qtile >= 0 overrides m0 / BM
   float* rowstat;             // producer side of the LayerNorm hand-over: [M][tiles_n][2] (sum, sum of squares) per output row and N-tile
   const float* ln_parts; int ln_np;   // consumer side: the producer's table, ln_np partial pairs per row
 };
@@ -233,7 +234,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
                                                int n0, int wm_off, int wn_off, int lrow, int lq, int split, int tid,
                                                const float* lnst = nullptr) {
   using E = EpiCfg<BM, BN>;
-  constexpr bool LEAN = EPI == 1, GLEAN = EPI == 2, SLEAN = EPI == 3;   // 3: split-K launches -- only the partial-tile store
+  // EPI 4 = LEAN + the GroupNorm-statistics hand-over (qstat): its own instantiation, so that the launches without it keep the
+  // compact code (with the statistics code compiled into every LEAN epilogue the short-K GEMMs ran 0.3-0.7 us slower each)
+  constexpr bool LEAN = EPI == 1 || EPI == 4, GLEAN = EPI == 2, SLEAN = EPI == 3;   // 3: split-K launches -- only the partial-tile store
+  constexpr bool QS = EPI == 0 || EPI == 4;
   float* Cs = reinterpret_cast<float*>(smem);
   if constexpr (LEAN && !VT) lnst = nullptr;               // LEAN keeps the V^T tile and the LayerNorm fold only in VT kernels
 
@@ -255,6 +259,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   bool ok[CH];
   f32x4 rb0[CH], rb1[CH];
   bf16x8 r1[CH], r2[CH];
+  // GroupNorm hand-over (p.qstat): this thread's partial (sum, sum of squares) of its two 4-channel quads, per image slot -- an
+  // M-tile of the generic kernels may run across the boundary between two images (slot 1 = rows of the second one)
+  int slot[CH];
+  float qacc[2][2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+  const int qb0 = (QS && p.qstat) ? fdiv(min(m0, p.M - 1), p.fd_ohw) : 0;
   auto phaseA = [&](int it0) {                               // addresses + every global read of rows it0 .. it0+CH-1
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
@@ -263,9 +272,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       rb0[u] = rb1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       r1[u] = r2[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       rowo[u] = 0;
+      slot[u] = 0;
       if (!ok[u]) continue;
       const int b = fdiv(m, p.fd_ohw);
       const int pix = m - b * p.OHW;
+      slot[u] = b != qb0;
       rowo[u] = (long long)b * p.out_bs + (long long)(pix * p.out_ps + p.out_po) * p.out_ld;
       if (p.rowbias) {
         const float* rb = p.rowbias + (long long)b * p.rowbias_ld + n;
@@ -356,6 +367,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
         if (vec) *reinterpret_cast<bf16x8*>(o) = t;       // (non-temporal stores: -7 % on isolated GEMMs, +1.2 % on the whole step)
         else
           for (int q = 0; q < 8; ++q) if (n + q < p.N) o[q] = t[q];
+        if (QS && p.qstat) {
+          float rs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};         // this row: [quad][sum, sum of squares] of the values as stored
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float f = (float)t[q];
+            rs[q >> 2][0] += f;
+            rs[q >> 2][1] = fmaf(f, f, rs[q >> 2][1]);
+          }
+          if (slot[u]) {                                     // (static register indices on both sides: no scratch)
+            qacc[1][0][0] += rs[0][0]; qacc[1][0][1] += rs[0][1]; qacc[1][1][0] += rs[1][0]; qacc[1][1][1] += rs[1][1];
+          } else {
+            qacc[0][0][0] += rs[0][0]; qacc[0][0][1] += rs[0][1]; qacc[0][1][0] += rs[1][0]; qacc[0][1][1] += rs[1][1];
+          }
+        }
         if (p.rowstat) {
           // LayerNorm hand-over: this row's sum / sum of squares over the tile's BN columns, of the values AS STORED (bf16).
           // The GPR threads of a row are consecutive lanes of one wave and are all active together (host-checked N % BN == 0).
@@ -547,6 +572,43 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
     for (int it0 = CH; it0 < ITERS; it0 += CH) {
       phaseA(it0);
       phaseB(std::false_type{}, it0);
+    }
+  }
+  if (QS && p.qstat) {
+    // fold the threads that share a column group (lanes l, l + GPR, ...; then the waves through LDS -- the fp32 image is dead:
+    // host-checked N % BN == 0, so every thread of the workgroup is here) and write the tile's table rows:
+    //   qstat[(tile * 2 + slot) * (N / 4) + quad][2]
+    __syncthreads();
+    float* red = Cs;                                         // [NT / 64 waves][GPR column groups][8]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float v = qacc[s2][qd][e];
+#pragma unroll
+          for (int o2 = GPR; o2 < 64; o2 <<= 1) v += __shfl_xor(v, o2, 64);
+          qacc[s2][qd][e] = v;
+        }
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane < GPR) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) red[(wv * GPR + lane) * 8 + s2 * 4 + qd * 2 + e] = qacc[s2][qd][e];
+    }
+    __syncthreads();
+    if (tid < GPR * 8) {
+      const int cg = tid >> 3, j = tid & 7;                  // column group, (slot, quad, which)
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NT / 64; ++w2) v += red[(w2 * GPR + cg) * 8 + j];
+      const int tile = p.qtile >= 0 ? p.qtile : m0 / BM;
+      const int quad = (n0 + cg * 8) / 4 + ((j >> 1) & 1);
+      p.qstat[(((long long)tile * 2 + (j >> 2)) * (p.N >> 2) + quad) * 2 + (j & 1)] = v;
     }
   }
 }
@@ -794,7 +856,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev p) {
-  constexpr bool LEAN = EPI == 1;
+  constexpr bool LEAN = EPI == 1 || EPI == 4;
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef ALDM_DIAG
   unsigned long long dg_t_entry; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_entry) :: "memory");
@@ -1215,6 +1277,14 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   if constexpr (S == 0) kern = igemm_kernel<BM, BN, WM, WN, RP, VT>;
   else kern = igemm_pipe_kernel<BM, BN, WM, WN, RP, VT, S, EPI>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm")) return rc;
+  if (d.qstat && !(EPI == 0 || EPI == 4)) {
+    aldm_set_error("igemm: qstat_out reached an epilogue instantiation without the statistics code (EPI %d)", EPI);
+    return ALDM_E_UNSUPPORTED;
+  }
+  if (d.qstat && d.N % BN != 0) {
+    aldm_set_error("igemm: qstat_out needs Cout %d to be a multiple of the tile width %d", d.N, BN);
+    return ALDM_E_ARG;
+  }
   if (d.rowstat && d.N % BN != 0) {
     aldm_set_error("igemm: rowstat_out needs Cout %d to be a multiple of the tile width %d", d.N, BN);
     return ALDM_E_ARG;
@@ -1255,6 +1325,7 @@ int launch_rp(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
       return launch_cfg<BM, BN, WM, WN, 0, false, S, 2>(d, st);          // GEGLU-only epilogue with a plain bf16 store
     // the common case -- standard epilogue, no activation -- runs the LEAN instantiation (nothing else compiled in)
     if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE && !d.ln_s) {
+      if (Rp == 0 && d.qstat) return launch_cfg<BM, BN, WM, WN, 0, false, S, 4>(d, st);   // + GroupNorm statistics
       if (Rp == 0) return launch_cfg<BM, BN, WM, WN, 0, false, S, 1>(d, st);
       if (Rp == 32) return launch_cfg<BM, BN, WM, WN, 32, false, S, 1>(d, st);
       return launch_cfg<BM, BN, WM, WN, 64, false, S, 1>(d, st);

@@ -23,7 +23,7 @@
 
 namespace aldm_igemm_detail {
 
-template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, bool LEAN>
+template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, int EPI /* 0 full, 1 lean, 4 lean + statistics */>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WM * WN == 8, "8 waves");
@@ -183,17 +183,18 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   // rows of this tile past the bottom of the image alias the next image's first rows: cut M for the epilogue's bound checks
   IgemmDev q = p;
   q.M = min(p.M, min(m0 + BM, (img + 1) * p.OHW));
-  igemm_epilogue<BM, BN, MI, NI, false, NT, LEAN ? 1 : 0>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
+  q.qtile = tile_m;                                         // GroupNorm hand-over table: one row per (image, tile in image), slot 0 only
+  igemm_epilogue<BM, BN, MI, NI, false, NT, EPI>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int HP, int S, bool LEAN>
+template <int BM, int BN, int WM, int WN, int HP, int S, int EPI>
 int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128;
   constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
-  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, LEAN>;
+  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_halo")) return rc;
   const int rows_pt = BM / d.OW;
   if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
@@ -211,8 +212,9 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int HP, int S>
 int launch_halo(const IgemmDev& d, hipStream_t st) {
-  if (d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE) return launch_halo_v<BM, BN, WM, WN, HP, S, true>(d, st);
-  return launch_halo_v<BM, BN, WM, WN, HP, S, false>(d, st);
+  if (d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE)
+    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1>(d, st);
+  return launch_halo_v<BM, BN, WM, WN, HP, S, 0>(d, st);
 }
 
 }  // namespace aldm_igemm_detail

@@ -9,6 +9,7 @@ int launch_w8(const IgemmDev& d, int Rp, bool vt, hipStream_t st) {
     return launch_cfg<128, 128, 4, 2, 64, true, S>(d, st);
   }
   if (d.splits <= 1 && !d.geglu && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE && !d.ln_s) {   // LEAN: see igemm_core.h
+    if (Rp == 0 && d.qstat) return launch_cfg<128, 128, 4, 2, 0, false, S, 4>(d, st);   // + GroupNorm statistics (EPI 4)
     if (Rp == 0) return launch_cfg<128, 128, 4, 2, 0, false, S, 1>(d, st);
     return launch_cfg<128, 128, 4, 2, 64, false, S, 1>(d, st);
   }

@@ -365,6 +365,22 @@ def _workspace(nbytes, device):
     return t
 
 
+@dataclass
+class QStats:
+    """GroupNorm statistics a convolution left next to its output (aldm_igemm qstat_out): per M-tile, image slot and 4-channel quad
+    the (sum, sum of squares) of the stored values.  Travels as the attribute `.qstats` of the output tensor; groupnorm() then
+    runs as one coalesced apply pass (aldm_groupnorm_apply).  bm: rows per generic M-tile; tpi > 0: image-aligned halo tiles."""
+    table: torch.Tensor
+    bm: int
+    tpi: int
+
+
+# Stand-alone GroupNorms read the statistics their producer handed over where that pays: big images (the strip-per-workgroup kernel
+# is L2-request-bound there) -- below this many pixels per image the register-resident kernel is as fast (HW = 1000: 6.7 us against
+# 10.0 us for fold + apply) and the producers' epilogues stay free of the statistics code.
+QSTATS_MIN_HW = 2048
+
+
 class Deferred:
     """A split-K convolution whose reduce is still pending (conv(..., defer=True)): the fp32 partial tiles sit in the shared
     workspace, `out` is the bf16 tensor the consumer will fill.  The ONLY valid consumer is the next groupnorm() call on this
@@ -403,7 +419,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
          splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None, x3=None, x4=None,
-         vt_dual=False):
+         vt_dual=False, qstats=False):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
@@ -542,6 +558,18 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if not ring:
         bm, bn = TILE_DIMS[tile]
         ring = pick_ring(tile, bm, bn, pw.Rp, math.ceil(M / bm) * math.ceil(pw.N / bn) * max(1, splits), ktiles)
+    qs = None
+    if (qstats and splits == 1 and vt is None and not pw.geglu and not out_f32 and out2 is None and out_pix_stride == 1
+            and not pw.Rp and pw.ln_s is None and not rowstats
+            and pw.N % 8 == 0 and pw.N % TILE_DIMS[tile][1] == 0 and out_ld == pw.N and OH * OW >= QSTATS_MIN_HW):
+        bm = TILE_DIMS[tile][0]
+        if tile in HALO_ROWS:
+            tpi = math.ceil(OH / (bm // OW))
+            qs = QStats(torch.empty(B * tpi, 2, pw.N // 4, 2, dtype=torch.float32, device=x.device), 0, tpi)
+        elif OH * OW >= bm:
+            qs = QStats(torch.empty(math.ceil(M / bm), 2, pw.N // 4, 2, dtype=torch.float32, device=x.device), bm, 0)
+        if qs is not None:
+            a.qstat_out = qs.table.data_ptr()
     stats = None
     if rowstats:
         if tile in HALO_ROWS or pw.N % TILE_DIMS[tile][1] or splits != 1:
@@ -562,6 +590,9 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     nbytes = 2.0 * (B * IH * IW * pw.Cin + M * pw.Cext + pw.N * ktot + M * ncols)
     label = (f"igemm_{TILE_NAMES[tile]}_r{pw.Rp}{'_vt' if vt is not None else ''}{'_sk' if splits > 1 else ''}"
              f"|M{M} N{pw.N} K{ktot}{' geglu' if pw.geglu else ''}")
+
+    if qs is not None:
+        out.qstats = qs                                     # (a Python attribute of this tensor object: skip lists keep the object)
 
     def finish():
         # the GroupNorm of gn=: over the partial tiles when the launch deferred its reduce, else over the bf16 output
@@ -630,6 +661,16 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load()
     n = B * H * W * (C1 + C2)
+    q1, q2 = getattr(x, "qstats", None), (getattr(x2, "qstats", None) if x2 is not None else None)
+    Cg = (C1 + C2) // groups
+    if (q1 is not None and (x2 is None or q2 is not None) and (C1 + C2) % groups == 0 and Cg % 4 == 0 and C1 % Cg == 0
+            and C1 % 8 == 0 and C2 % 8 == 0 and groups <= 64 and x.is_contiguous() and (x2 is None or x2.is_contiguous())):
+        # one coalesced pass: the producing convolution(s) handed the statistics over
+        check(_launch(f"groupnorm_apply|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm_apply(
+            _p(x), _p(q1.table), q1.bm, q1.tpi, _p(x2), _p(q2.table) if q2 is not None else None, q2.bm if q2 is not None else 0,
+            q2.tpi if q2 is not None else 0, B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())),
+            "aldm_groupnorm_apply")
+        return y
     check(_launch(f"groupnorm|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(
         _p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm")
     return y

@@ -249,20 +249,22 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=No
     x = ops.tensor_of(x)
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
     # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
-    h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=(P.g2, P.b2, P.groups, P.eps, ACT_SILU))
+    # (qstats=True: a launch that does not split K leaves GroupNorm statistics next to its output, so the norm that consumes it --
+    #  here norm2, below the next block's norm1 / the Transformer2DModel's norm -- is one coalesced apply pass)
+    h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=(P.g2, P.b2, P.groups, P.eps, ACT_SILU), qstats=True)
     if P.conv2s is not None and (x2 is None or x2.shape[3] % 64 == 0) and x.shape[3] % 64 == 0:
         # the 1x1 shortcut over the block input (| skip) rides at the end of conv2's K loop: one launch instead of two
         if next_gn is not None:
-            return ops.conv(h, P.conv2s, pad=(1, 1), x3=x, x4=x2, gn=next_gn, gn_keep=True)
-        return ops.conv(h, P.conv2s, pad=(1, 1), x3=x, x4=x2, defer=(defer or False))
+            return ops.conv(h, P.conv2s, pad=(1, 1), x3=x, x4=x2, gn=next_gn, gn_keep=True, qstats=True)
+        return ops.conv(h, P.conv2s, pad=(1, 1), x3=x, x4=x2, defer=(defer or False), qstats=True)
     if P.shortcut is not None:
         xs = ops.conv(x, P.shortcut, x2=x2)
     else:
         assert x2 is None
         xs = x
     if next_gn is not None:
-        return ops.conv(h, P.conv2, pad=(1, 1), res=xs, gn=next_gn, gn_keep=True)
-    return ops.conv(h, P.conv2, pad=(1, 1), res=xs, defer=(defer or False))
+        return ops.conv(h, P.conv2, pad=(1, 1), res=xs, gn=next_gn, gn_keep=True, qstats=True)
+    return ops.conv(h, P.conv2, pad=(1, 1), res=xs, defer=(defer or False), qstats=True)
 
 
 def run_attention(P, hn, h_res, B, N, fp8=False, ln_parts=None, rowstats=False):
@@ -308,9 +310,9 @@ def run_transformer(P, x, fp8=False, xn=None, defer=None):
         h, st = h
     g = ops.linear(h if f3 else ops.layernorm(h, *P.ln[2]), P.ff1, ln_parts=st)
     if P.ff2_proj is not None:                                # ff2 and proj_out as ONE GEMM over the virtual concat [g | h]
-        return ops.conv(g.view(B, H, W, 4 * C), P.ff2_proj, x2=h.view(B, H, W, C), res=x, defer=(defer or False))
+        return ops.conv(g.view(B, H, W, 4 * C), P.ff2_proj, x2=h.view(B, H, W, C), res=x, defer=(defer or False), qstats=True)
     h = ops.linear(g, P.ff2, res=h)
-    return ops.conv(h.view(B, H, W, C), P.proj_out, res=x, defer=(defer or False))
+    return ops.conv(h.view(B, H, W, C), P.proj_out, res=x, defer=(defer or False), qstats=True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -486,7 +488,7 @@ class UNet2DConditionModel(nn.Module):
             ops.linear(class_labels_bf16, P.cls, out_act=ACT_SILU, out=semb[:, ted:], out_ld=2 * ted)
             rowbias = ops.linear(semb, P.temb_all, out_f32=True)
 
-        h = ops.conv(x, P.conv_in, pad=(1, 1))
+        h = ops.conv(x, P.conv_in, pad=(1, 1), qstats=True)
         skips = [h]
         # `nxt` = (channels, groups) of the GroupNorm that consumes a block's output next (norm1 of the following ResnetBlock2D,
         # over torch.cat([h, skip]) on the way up): a split-K producer then leaves its reduce to that norm (ops.Deferred)
@@ -509,7 +511,7 @@ class UNet2DConditionModel(nn.Module):
                     h = run_resnet(r, h, None, rowbias, ld, defer=nxt)
                 skips.append(ops.tensor_of(h))
             if blk.down is not None:
-                h = ops.conv(h, blk.down, stride=(2, 2), pad=(1, 1), defer=norm1_of(P.down[bi + 1].resnets[0]))
+                h = ops.conv(h, blk.down, stride=(2, 2), pad=(1, 1), defer=norm1_of(P.down[bi + 1].resnets[0]), qstats=True)
                 skips.append(ops.tensor_of(h))
         h, hn = run_resnet(P.mid.resnets[0], h, None, rowbias, ld, next_gn=transformer_gn(P.mid.attns[0]))
         h = run_transformer(P.mid.attns[0], h, fp8, xn=hn, defer=norm1_of(P.mid.resnets[1]))
@@ -533,7 +535,7 @@ class UNet2DConditionModel(nn.Module):
                     size = (skips[-1].shape[1], skips[-1].shape[2])
                 else:
                     size = (h.shape[1] * 2, h.shape[2] * 2)
-                h = ops.conv(h, blk.up, pad=(1, 1), up_size=size, defer=norm1_of(P.up[bi + 1].resnets[0]))
+                h = ops.conv(h, blk.up, pad=(1, 1), up_size=size, defer=norm1_of(P.up[bi + 1].resnets[0]), qstats=True)
         h = ops.groupnorm(h, P.gn_out[0], P.gn_out[1], groups, eps, ACT_SILU)
         return ops.conv(h, P.conv_out, pad=(1, 1), out_f32=True)
 

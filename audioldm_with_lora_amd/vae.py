@@ -125,7 +125,7 @@ def run_vae_attention(P, x):
         vt = torch.zeros(B, C, npad, dtype=torch.bfloat16, device=x.device)       # keys beyond N must read as zeros
         qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad)
         o = ops.attention_wide(qk.view(B * N, 2 * C), vt, B, N, C)
-        return ops.linear(o, P.out, res=x.view(B * N, C)).view(B, H, W, C)
+        return ops.conv(o.view(B, H, W, C), P.out, res=x, qstats=True)
     q = ops.linear(hn, P.q)
     k = ops.linear(hn, P.k)
     npad = (N + 63) // 64 * 64
@@ -224,7 +224,7 @@ class AutoencoderKL(nn.Module):
         P = self.plan()
         D = P.dec
         h = ops.conv(z, P.post_quant)
-        h = ops.conv(h, D.conv_in, pad=(1, 1))
+        h = ops.conv(h, D.conv_in, pad=(1, 1), qstats=True)
         h = run_resnet(D.mid_res[0], h)
         h = run_vae_attention(D.mid_attn, h)
         h = run_resnet(D.mid_res[1], h)
@@ -232,7 +232,7 @@ class AutoencoderKL(nn.Module):
             for r in u.resnets:
                 h = run_resnet(r, h)
             if u.up is not None:
-                h = ops.conv(h, u.up, pad=(1, 1), up_size=(h.shape[1] * 2, h.shape[2] * 2))
+                h = ops.conv(h, u.up, pad=(1, 1), up_size=(h.shape[1] * 2, h.shape[2] * 2), qstats=True)
         h = ops.groupnorm(h, D.gn[0], D.gn[1], D.groups, EPS, ACT_SILU)
         return ops.conv(h, D.conv_out, pad=(1, 1), out_f32=True)
 
@@ -258,15 +258,15 @@ class AutoencoderKL(nn.Module):
                 w8 = torch.zeros(w.shape[0], 8, 3, 3, device=w.device, dtype=w.dtype)
                 w8[:, :C] = w
                 E.conv_in8 = ops.pack_conv(w8, self.encoder.conv_in.bias)
-            h = ops.conv(x, E.conv_in8, pad=(1, 1))
+            h = ops.conv(x, E.conv_in8, pad=(1, 1), qstats=True)
         else:
-            h = ops.conv(x, E.conv_in, pad=(1, 1))
+            h = ops.conv(x, E.conv_in, pad=(1, 1), qstats=True)
         for d in E.downs:
             for r in d.resnets:
                 h = run_resnet(r, h)
             if d.down is not None:                           # F.pad(x, (0,1,0,1)) + stride-2 conv, pad folded into bounds
                 oh, ow = h.shape[1] // 2, h.shape[2] // 2
-                h = ops.conv(h, d.down, stride=(2, 2), pad=(0, 0), out_hw=(oh, ow))
+                h = ops.conv(h, d.down, stride=(2, 2), pad=(0, 0), out_hw=(oh, ow), qstats=True)
         h = run_resnet(E.mid_res[0], h)
         h = run_vae_attention(E.mid_attn, h)
         h = run_resnet(E.mid_res[1], h)

@@ -102,6 +102,11 @@ typedef struct {
      activation tiles in the K loop -- the LayerNorm launch disappears and no GEMM pays for the statistics twice. */
   float* rowstat_out;
   const float* ln_parts;  int ln_nparts;
+  /* GroupNorm statistics handed to aldm_groupnorm_apply: per M-tile of the launch, per image slot (0: the image of the tile's
+     first row, 1: the next image -- an M-tile of the generic kernels may cross one image boundary; the halo tiles are
+     image-aligned and use slot 0 only) and per 4-channel quad, the (sum, sum of squares) of the bf16 values stored:
+     qstat_out [tiles_m][2][Cout / 4][2] fp32.  Standard bf16 epilogue only, Cout a multiple of the tile width. */
+  float* qstat_out;
   /* A 1x1 convolution over a SECOND pair of sources, accumulated into the same output tile: K grows by Cin3 + Cin4 columns
      appended to every weight row (w [Cout][KH*KW*(Cin+Cin2) | Cin3+Cin4]).  x3 (| x4) are bf16 [B][OH][OW][Cin3 (Cin4)], i.e.
      they have the OUTPUT's spatial extent.  This is ResnetBlock2D's `conv_shortcut(input) + conv2(h)` as ONE launch
@@ -133,6 +138,14 @@ int aldm_igemm_effective_splits(const aldm_igemm_t* p);
  * ------------------------------------------------------------------------------------------ */
 int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2, int groups, float eps,
                    const float* gamma, const float* beta, int act, void* y, void* stream);
+
+/* GroupNorm (+SiLU) over cat[x, x2] in ONE coalesced pass, with the statistics handed over by the aldm_igemm launches that
+   produced x (and x2): qstat / qstat2 are their qstat_out tables; bm = rows per M-tile of the producing launch (generic
+   tiles, bm <= HW), or tpi > 0 = tiles per image of an image-aligned (halo) launch.  Same arithmetic as aldm_groupnorm
+   (F.group_norm under ResnetBlock2D.norm1/2, conv_norm_out, the VAE's norms), variance as E[x^2] - mean^2 in fp32. */
+int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, int tpi, const void* x2, const float* qstat2, int bm2, int tpi2,
+                         int B, int HW, int C1, int C2, int groups, float eps, const float* gamma, const float* beta, int act,
+                         void* y, void* stream);
 
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
 int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,

@@ -295,6 +295,53 @@ def test_groupnorm(ops, B, HW, C1, C2, groups, act):
     close(to_nchw(y), want)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,groups,tile", [
+    (3, 130, 16, 128, 0, 32, 0),       # 2080 pixels per image: 64 / 128-row M-tiles cross image boundaries (slot 1)
+    (2, 128, 16, 128, 128, 32, 7),     # halo tiles (image-aligned) for x; second source from a generic launch; Cg = 8
+    (2, 250, 16, 192, 192, 32, 0),     # Cg = 12: a 16-byte unit spans two groups; 48 units per pixel (idle remainder threads)
+    (1, 136, 16, 64, 0, 8, 2),
+    (2, 250, 16, 128, 0, 32, 6),       # the 8-wave 128x128 tile
+    (2, 250, 16, 128, 0, 32, 1),
+    (2, 250, 16, 128, 0, 32, 3),
+    (2, 250, 16, 128, 0, 32, 4),
+    (2, 128, 16, 128, 0, 32, 8),       # halo 64x128
+])
+def test_groupnorm_apply_from_conv_statistics(ops, B, H, W, C1, C2, groups, tile):
+    """GroupNorm whose statistics were handed over by the producing convolutions (aldm_igemm qstat_out ->
+    aldm_groupnorm_apply): conv3x3 -> [cat with a second conv's output] -> GroupNorm(+SiLU) vs torch."""
+    g = torch.Generator().manual_seed(31)
+    x = bf(torch.randn(B, 64, H, W, generator=g))
+    w1 = bf(torch.randn(C1, 64, 3, 3, generator=g) * 0.06)
+    b1 = torch.randn(C1, generator=g)
+    y1 = ops.conv(nhwc(x), ops.pack_conv(w1.to(DEV), b1.to(DEV)), pad=(1, 1), tile=tile, ring=((2 if tile == 6 else 3) if tile else 0), splits=1,
+                  qstats=True)
+    assert getattr(y1, "qstats", None) is not None, "the convolution did not leave statistics"
+    want1 = F.conv2d(x, w1, b1, padding=1)
+    y2 = want2 = None
+    if C2:
+        w2 = bf(torch.randn(C2, 64, 1, 1, generator=g) * 0.2)
+        y2 = ops.conv(nhwc(x), ops.pack_conv(w2.to(DEV), None), splits=1, qstats=True)
+        assert getattr(y2, "qstats", None) is not None
+        want2 = F.conv2d(x, w2)
+    gm, bt = torch.randn(C1 + C2, generator=g), torch.randn(C1 + C2, generator=g)
+    before = ops.PROFILE
+    ops.PROFILE = []
+    got = ops.groupnorm(y1, gm.to(DEV), bt.to(DEV), groups, 1e-5, 1, x2=y2)
+    labels = [r[0] for r in ops.PROFILE]
+    ops.PROFILE = before
+    assert labels and labels[0].startswith("groupnorm_apply"), labels
+    # reference on the bf16-rounded conv outputs (what the norm really reads)
+    xin = torch.cat([to_nchw(y1)] + ([to_nchw(y2)] if C2 else []), 1)
+    close(to_nchw(y1), want1, rtol=2e-2)
+    want = F.silu(F.group_norm(xin, groups, gm, bt, 1e-5))
+    close(to_nchw(got), want, rtol=2e-2)
+    # and the stand-alone kernel on the same tensors agrees
+    y1b = y1.clone()
+    y2b = y2.clone() if C2 else None
+    ref = ops.groupnorm(y1b, gm.to(DEV), bt.to(DEV), groups, 1e-5, 1, x2=y2b)
+    close(to_nchw(got), to_nchw(ref).float(), rtol=1e-2, atol=2e-2)
+
+
 def test_layernorm(ops):
     g = torch.Generator().manual_seed(8)
     for Cc in (64, 96, 256, 640):

@@ -36,7 +36,7 @@ voc.forward_nhwc(melb)
 vae.decode_nhwc(z)
 torch.cuda.synchronize()
 agg = {}
-for label, fl, by, s, e in ops.PROFILE:
+for label, fl, by, s, e, _site in ops.PROFILE:
     a = agg.setdefault(label, [0.0, 0, 0.0])
     a[0] += s.elapsed_time(e); a[1] += 1; a[2] += fl
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
