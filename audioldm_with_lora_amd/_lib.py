@@ -117,6 +117,8 @@ PROTOTYPES = {
     "aldm_cfg_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aldm_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "aldm_add_noise_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "aldm_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
     "aldm_sleep_us": (C.c_int, [C.c_int, C.c_void_p]),
     "aldm_gather_row": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "aldm_advance_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

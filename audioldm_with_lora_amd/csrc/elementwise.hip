@@ -124,6 +124,30 @@ __global__ void add_noise_kernel(const float* __restrict__ x, const float* __res
   out[idx] = coef[2 * b] * x[idx] + coef[2 * b + 1] * nz[idx];
 }
 
+// add_noise with the coefficients taken on the device: noisy = sqrt(abar[t_b]) x + sqrt(1 - abar[t_b]) noise  (t int64 per sample)
+__global__ void add_noise_t_kernel(const float* __restrict__ x, const float* __restrict__ nz, const float* __restrict__ abar,
+                                   const long long* __restrict__ t, int n_train, int B, long long n, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * n) return;
+  const int b = (int)(idx / n);
+  long long tb = t[b];
+  tb = tb < 0 ? 0 : (tb >= n_train ? n_train - 1 : tb);
+  const float a = abar[tb];
+  out[idx] = sqrtf(a) * x[idx] + sqrtf(1.f - a) * nz[idx];
+}
+
+// DiagonalGaussianDistribution.sample(): params NCHW [B][2C][HW] = (mean | logvar), noise / out [B][C][HW]:
+// out = mean + exp(0.5 clamp(logvar, -30, 20)) * noise   (vae.encode(x).latent_dist.sample() [REF train:495])
+__global__ void gaussian_sample_kernel(const float* __restrict__ params, const float* __restrict__ nz, int B, long long chw,
+                                       float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * chw) return;
+  const long long b = idx / chw, r = idx - b * chw;
+  const float mean = params[b * 2 * chw + r];
+  const float lv = fminf(fmaxf(params[b * 2 * chw + chw + r], -30.f), 20.f);
+  out[idx] = mean + __expf(0.5f * lv) * nz[idx];
+}
+
 // Holds the stream busy for ~us microseconds (one wave polling the 100 MHz real-time counter).  Measurement aid: lets a
 // host that enqueues slower than the GPU executes build up a queue, so per-kernel event pairs time kernels, not host gaps.
 __global__ void sleep_kernel(unsigned long long ticks) {
@@ -177,6 +201,21 @@ extern "C" int aldm_add_noise(const float* x, const float* noise, const float* c
   ALDM_CHECK_ARG(x && noise && coef && out && B > 0 && n_per_sample > 0, "add_noise: bad args");
   hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x, noise, coef, B, n_per_sample, out);
   return aldm_launch_status("add_noise");
+}
+
+extern "C" int aldm_add_noise_t(const float* x, const float* noise, const float* alphas_cumprod, const long long* timesteps,
+                                int n_train, int B, long long n_per_sample, float* out, void* stream) {
+  ALDM_CHECK_ARG(x && noise && alphas_cumprod && timesteps && out && B > 0 && n_per_sample > 0 && n_train > 0, "add_noise_t: bad args");
+  hipLaunchKernelGGL(add_noise_t_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x, noise,
+                     alphas_cumprod, timesteps, n_train, B, n_per_sample, out);
+  return aldm_launch_status("add_noise_t");
+}
+
+extern "C" int aldm_gaussian_sample(const float* params, const float* noise, int B, long long chw, float* out, void* stream) {
+  ALDM_CHECK_ARG(params && noise && out && B > 0 && chw > 0, "gaussian_sample: bad args");
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3(blocks_for((long long)B * chw, 256)), dim3(256), 0, (hipStream_t)stream, params, noise,
+                     B, chw, out);
+  return aldm_launch_status("gaussian_sample");
 }
 
 extern "C" int aldm_sleep_us(int us, void* stream) {

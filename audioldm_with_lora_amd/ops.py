@@ -808,6 +808,28 @@ def add_noise(x, noise, coef):
     return out.to(x.dtype)
 
 
+def add_noise_t(x, noise, alphas_cumprod, timesteps):
+    """DDIMScheduler.add_noise with device-side coefficients: x, noise fp32 [B, ...], alphas_cumprod fp32 [T], timesteps int64 [B]."""
+    _require_gpu(x)
+    B = x.shape[0]
+    xf, nf = x.float().contiguous(), noise.float().contiguous()
+    assert alphas_cumprod.dtype == torch.float32 and timesteps.dtype == torch.int64 and timesteps.numel() == B
+    out = torch.empty_like(xf)
+    check(_lib.load().aldm_add_noise_t(_p(xf), _p(nf), _p(alphas_cumprod), _p(timesteps.contiguous()), alphas_cumprod.numel(), B,
+                                       xf.numel() // B, _p(out), _stream()), "aldm_add_noise_t")
+    return out.to(x.dtype)
+
+
+def gaussian_sample(params_nchw, noise):
+    """mean + exp(0.5 clamp(logvar)) * noise for params [B, 2C, H, W] fp32 (mean | logvar), noise [B, C, H, W] fp32."""
+    _require_gpu(params_nchw)
+    B, C2 = params_nchw.shape[:2]
+    pf, nf = params_nchw.float().contiguous(), noise.float().contiguous()
+    out = torch.empty_like(nf)
+    check(_lib.load().aldm_gaussian_sample(_p(pf), _p(nf), B, nf.numel() // B, _p(out), _stream()), "aldm_gaussian_sample")
+    return out
+
+
 def sleep_us(us):
     check(_lib.load().aldm_sleep_us(int(us), _stream()), "aldm_sleep_us")
 

@@ -81,7 +81,8 @@ class DDIMScheduler:
         return SimpleNamespace(prev_sample=x.to(sample.dtype))
 
     def add_noise(self, original_samples, noise, timesteps):
-        ac = self.alphas_cumprod.to(original_samples.device)
-        t = timesteps.to(original_samples.device)
-        coef = torch.stack([ac[t] ** 0.5, (1 - ac[t]) ** 0.5], dim=1).float().contiguous()
-        return ops.add_noise(original_samples, noise, coef)
+        dev = original_samples.device
+        ac = self._dev.get(("ac", dev))
+        if ac is None:
+            ac = self._dev[("ac", dev)] = self.alphas_cumprod.to(dev, torch.float32).contiguous()
+        return ops.add_noise_t(original_samples, noise, ac, timesteps.to(dev, torch.int64).reshape(-1))

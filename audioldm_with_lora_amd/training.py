@@ -589,9 +589,7 @@ class LoraTrainer:
         f.grads.zero_()
         if self.ac_dev is None:
             raise ops._lib.AldmError("LoraTrainer.step needs the noise scheduler (pass scheduler= to the constructor)")
-        ac = self.ac_dev[timesteps]
-        coef = torch.stack([ac ** 0.5, (1 - ac) ** 0.5], dim=1).contiguous()
-        noisy = ops.add_noise(latents, noise, coef)
+        noisy = ops.add_noise_t(latents, noise, self.ac_dev, timesteps)      # coefficients looked up on the device: one launch
         x_in = ops.nchw_to_nhwc(noisy)
         tgt = ops.nchw_to_nhwc(noise, out_f32=True)
         t_dev = timesteps.to(torch.float32)

@@ -145,14 +145,24 @@ def run_vae_attention(P, x):
 
 
 class DiagonalGaussian:
+    """diffusers' DiagonalGaussianDistribution over encoder moments [B, 2C, H, W] (mean | logvar).  `sample()` is one HIP kernel
+    (clamp, exp, multiply-add); `mean` / `mode()` are views; `logvar` / `std` exist for inspection and are derived lazily."""
+
     def __init__(self, params_nchw):
-        self.mean, logvar = params_nchw.chunk(2, dim=1)
-        self.logvar = logvar.clamp(-30.0, 20.0)
-        self.std = torch.exp(0.5 * self.logvar)
+        self.parameters = params_nchw
+        self.mean = params_nchw.chunk(2, dim=1)[0]
+
+    @property
+    def logvar(self):
+        return self.parameters.chunk(2, dim=1)[1].clamp(-30.0, 20.0)
+
+    @property
+    def std(self):
+        return torch.exp(0.5 * self.logvar)
 
     def sample(self, generator=None):
-        noise = torch.randn(self.mean.shape, generator=generator, dtype=self.mean.dtype, device=self.mean.device)
-        return self.mean + self.std * noise
+        noise = torch.randn(self.mean.shape, generator=generator, dtype=torch.float32, device=self.mean.device)
+        return ops.gaussian_sample(self.parameters, noise).to(self.mean.dtype)
 
     def mode(self):
         return self.mean

@@ -257,6 +257,13 @@ int aldm_gather_row(const float* table, const int* idx, long long row_elems, flo
    [REF script/train/train_audioldm_lora.py:504]); fp32 in, fp32 out; coef fp32 [B][2] = {sqrt(abar_t), sqrt(1-abar_t)} */
 int aldm_add_noise(const float* x, const float* noise, const float* coef, int B, long long n_per_sample, float* out,
                    void* stream);
+/* the same with the coefficients looked up on the device: alphas_cumprod fp32 [n_train], timesteps int64 [B] (device) --
+   `noise_scheduler.add_noise(latents, noise, timesteps)` [REF script/train/train_audioldm_lora.py:503-504] as one launch */
+int aldm_add_noise_t(const float* x, const float* noise, const float* alphas_cumprod, const long long* timesteps, int n_train,
+                     int B, long long n_per_sample, float* out, void* stream);
+/* DiagonalGaussianDistribution.sample(): params fp32 NCHW [B][2C][HW] = (mean | logvar), noise / out fp32 [B][C][HW], chw = C*HW:
+   out = mean + exp(0.5 clamp(logvar, -30, 20)) noise  -- `vae.encode(x).latent_dist.sample()` [REF train:495] */
+int aldm_gaussian_sample(const float* params, const float* noise, int B, long long chw, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward kernels of the LoRA fine-tune step [REF script/train/train_audioldm_lora.py:499-565]: the base model

@@ -85,6 +85,10 @@ def test_vae_encode_matches_oracle():
     assert got.mean.shape == want.mean.shape == (2, 8, 10, 4)
     assert rel_l2(got.mean.cpu(), want.mean) < 4e-2
     assert rel_l2(got.std.cpu(), want.std) < 4e-2
+    # latent_dist.sample() [REF train:495] is one kernel: mean + exp(0.5 clamp(logvar)) * noise with the generator's noise
+    s1 = got.sample(torch.Generator(device="cuda").manual_seed(3))
+    noise = torch.randn(got.mean.shape, generator=torch.Generator(device="cuda").manual_seed(3), dtype=torch.float32, device="cuda")
+    torch.testing.assert_close(s1.float(), got.mean.float() + got.std.float() * noise, rtol=1e-5, atol=1e-6)
 
 
 def test_pipeline_end_to_end_config1_shape_tiny_models():
