@@ -1,0 +1,335 @@
+// ONE launch for the front half of the fused-LoRA attention module at the UNet's 64-token level (C = 640, 8 heads x 80,
+// N = 32 x 2 = 64 tokens per sample; 12 of the 32 Attention modules of UNet2DConditionModel.forward
+// [REF script/train/train_audioldm_lora.py:539-546] / the DDIM loop [REF script/inference/generate_audio.py:47-52]):
+//     LayerNorm (folded) -> to_q | to_k | to_v with the LoRA side channel -> softmax(Q K^T) V        per (sample, head) workgroup.
+// Why: at this level every launch is a 6-13 us latency chain for a few hundred MFLOP.  A (sample, head) workgroup can hold the
+// sample's whole hidden state (64 x 640 bf16 = 80 KB) in LDS, stream only ITS 240 weight rows (+ the LoRA-A rows) through a
+// two-stage LDS-DMA ring, keep Q / K / V^T of the head in LDS (37 KB) and run the 64 x 64 attention on them -- Q | K | V never
+// touch HBM and two launches (19 us) become one.  SURVEY.md 2.3 K1 ("fused QKV-GEMM + LoRA epilogue -> flash-style attention").
+//
+//   * 4 wave64; wave w owns tokens 16 w .. 16 w + 15 through both phases.  v_mfma_f32_16x16x32_bf16, issued "swapped" (weight rows
+//     = A operand) so a lane owns ONE token column: LayerNorm mean / rstd and the softmax state are lane-local.
+//   * the weight stream goes HBM/L2 -> registers -> LDS: plain 16-byte loads, six tiles (20 KB + the tile's 1 KB of LoRA-B rows)
+//     in flight per workgroup, ds_write_b128 into a double-buffered swizzled image.  (With one workgroup per CU the LDS-DMA path
+//     is the bottleneck -- one 1 KB piece per ~60 cycles per CU, measured with in-kernel stamps: 1250 cycles per tile against 600
+//     for this form.)  Only X, needed once, comes by LDS-DMA.  No small global load sits inside the tile loop: s_n | c_n of the
+//     head's 240 columns are parked in LDS up front.
+//   * projection: X fragments of the wave's 16 tokens stay in registers (20 k-steps x 4 VGPRs) across all 17 weight tiles
+//     (1-2 LoRA-A tiles first: T = X A'^T, then 5 q + 5 k + 5 v tiles of 16 output columns); LoRA: T'' = T - mean sA + cA / rstd is
+//     rounded to bf16 in registers and enters every tile as one more K = 32 step against the pre-scaled B rows (k order =
+//     accumulator row permutation, reproduced by two 8-byte reads of B); epilogue y = rstd (acc - mean s_n) + c_n as in aldm_igemm.
+//   * attention: S^T = K Q^T (4 key tiles x 3 k-steps); Q never leaves registers -- the projection's accumulator layout IS a
+//     B operand once K is read with the matching k-slot order; softmax over the 64 keys in registers (Q is pre-scaled by
+//     d^-0.5 log2 e at pack time), O^T = V^T P^T with the S^T accumulators re-used as the B operand.
+#include "igemm_core.h"   // make_rsrc / lds_ptr_t / wait_vmcnt
+
+namespace {
+
+using aldm_igemm_detail::lds_ptr_t;
+using aldm_igemm_detail::wait_vmcnt;
+
+struct Blk64Args {
+  const bf16* x;            // [B * N][C] raw hidden state
+  const float* ln_parts;    // [B * N][np][2] row partials from the producer of x
+  const bf16* w;            // [3C][Kpad] LayerNorm-folded q | k | v weights (q pre-scaled)
+  const float* bias;        // [3C] c_n = W beta (+ bias)
+  const float* ln_s;        // [3C] row sums of the folded weights
+  const bf16* lora_a;       // [Rp][Kpad] folded LoRA-A rows of q | k | v (or null)
+  const bf16* lora_b;       // [3C][Rp] pre-scaled LoRA-B
+  const float* ln_sa;       // [Rp]
+  const float* ln_ca;       // [Rp]
+  bf16* out;                // [B * N][C] attention output (heads concatenated)
+  int np, Kpad, Rp, N, H;
+  float eps;
+  unsigned long long* diag;   // tools/debug_b64.py: s_memtime stamps of workgroup (0, 0), wave 0 (null in production)
+};
+
+#ifdef ALDM_B64_DIAG   // stamps are compiled in only on request: even a never-taken branch perturbs the wait-count bookkeeping
+#define B64_STAMP(i) if (p.diag && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.diag[i] = t_; }
+#else
+#define B64_STAMP(i)
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int C, int D, int RT /* LoRA rank tiles of 16: 0, 1 or 2 */>
+__global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NTOK = 64, CPR = C / 8;                      // 16-byte chunks per row
+  constexpr int KSTEPS = C / 32;
+  constexpr int DTL = D / 16;                                 // 16-column tiles per q / k / v section
+  constexpr int NTILES = RT + 3 * DTL;
+  constexpr int DKS = (D + 31) / 32;                          // k-steps of the Q K^T contraction
+  constexpr int KSTR = D * 2 + 16;                            // K row stride (odd multiple of 16 B: conflict-free ds_read_b64)
+  constexpr int VSTR = NTOK * 2 + 8;                          // V^T row stride: conflict-free ds_read_b64
+  constexpr int WTILE = 16 * C * 2, WSTAGE = WTILE + 1024;    // weight tile + its 16 x 32 LoRA-B rows
+  constexpr int P = 5;                                        // weight tiles in flight in registers, behind the (up to) two waiting in LDS
+  constexpr int NS = 3;                                       // LDS stages: tile t is multiplied while t + 1 is read and t + 2 written
+  static_assert(CPR % 16 == 0 && D % 16 == 0 && WTILE / 1024 == 20, "C = 640; D % 16 == 0");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Wr = smem;                                      // [NS][WSTAGE]
+  char* const Ks = Wr + NS * WSTAGE;                          // [64][KSTR]
+  char* const Vt = Ks + NTOK * KSTR;                          // [D][VSTR]
+  float* const sn_l = reinterpret_cast<float*>(Vt + D * VSTR);   // [3 D] row sums s_n of this head's q | k | v columns
+  float* const cn_l = sn_l + 3 * D;                               // [3 D] c_n
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int N = p.N;
+  const long long row0 = (long long)b * N;
+  const int tok = 16 * wave + n;
+  const bool live = tok < N;
+  B64_STAMP(0)
+
+  const __amdgpu_buffer_rsrc_t rs_x = aldm_igemm_detail::make_rsrc(p.x + row0 * C, (unsigned)(N * C * 2));
+  const __amdgpu_buffer_rsrc_t rs_w = aldm_igemm_detail::make_rsrc(p.w, (unsigned)(3u * C * (unsigned)p.Kpad * 2u));
+  const __amdgpu_buffer_rsrc_t rs_a = aldm_igemm_detail::make_rsrc(RT ? (const void*)p.lora_a : (const void*)p.w, (unsigned)((RT ? p.Rp : 16) * p.Kpad * 2));
+  const __amdgpu_buffer_rsrc_t rs_b = aldm_igemm_detail::make_rsrc(RT ? (const void*)p.lora_b : (const void*)p.w, (unsigned)(RT ? 3u * C * (unsigned)p.Rp * 2u : 64u));
+
+  // ---- the small operands first (vmcnt retires in order: nothing issued later may be waited on through them) ----
+  float ln_a = 0.f, ln_q = 0.f;
+  if (live) {
+    const float* pp = p.ln_parts + (row0 + tok) * (p.np * 2);
+    float2 v[16];                                            // all partials in flight at once (a running sum would wait per load)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = j < p.np ? *reinterpret_cast<const float2*>(pp + 2 * j) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { ln_a += v[j].x; ln_q += v[j].y; }
+  }
+  float sn_v = 0.f, cn_v = 0.f;
+  if (tid < 3 * D) {
+    const int sec = tid / D, r = tid - sec * D;
+    sn_v = p.ln_s[sec * C + head * D + r];
+    cn_v = p.bias[sec * C + head * D + r];
+  }
+  f32x4 sa[RT ? RT : 1], ca[RT ? RT : 1];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    sa[t] = *reinterpret_cast<const f32x4*>(p.ln_sa + 16 * t + 4 * g);
+    ca[t] = *reinterpret_cast<const f32x4*>(p.ln_ca + 16 * t + 4 * g);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- X fragments of this wave's 16 tokens straight into registers (B operand): lane (n, g) holds X[16 w + n][32 ks + 8 g .. + 7].
+  //      They stay there across all weight tiles, so X never needs LDS; rows >= N read as zeros through the descriptor. ----
+  bf16x8 xf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+    xf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, tok * (C * 2) + (32 * ks + 8 * g) * 2, 0, 0));
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- the weight stream: HBM/L2 -> registers (plain 16-byte loads, P tiles in flight) -> LDS (NS stages) ----
+  // Tile t: LoRA-A rows first, then q | k | v rows of this head; 16 rows x CPR chunks = 5 loads per lane; wave (t & 3) also fetches
+  // the tile's LoRA-B rows [16][first 32 ranks] (1 KB).  (Plain loads, not LDS-DMA: a DMA piece costs its wave ~60 issue cycles
+  // and with one wave per SIMD every issue cycle is on the critical path.)
+  auto wrow0 = [&](int t) {
+    const int j = t - RT, sec = j / DTL, jj = j - sec * DTL;
+    return sec * C + head * D + 16 * jj;
+  };
+  int w_src[5], w_dst[5];                                      // per-lane chunk of a tile: source byte offset (row-relative), swizzled LDS offset
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int c = (wave + 4 * i) * 64 + lane, row = c / CPR, ph = c - row * CPR;
+    w_src[i] = row * (p.Kpad * 2) + ph * 16;
+    w_dst[i] = row * (C * 2) + ((ph ^ (row & 15)) * 16);
+  }
+  const int b_src = (lane >> 2) * (p.Rp * 2) + (lane & 3) * 16;
+  u32x4 wreg[P][5], breg[P];
+  auto gload = [&](int t) {
+    const int slot = t % P;
+    const bool la = t < RT;
+    const int r0 = la ? 16 * t : wrow0(t);
+    const int base = r0 * (p.Kpad * 2);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(la ? rs_a : rs_w, base + w_src[i], 0, 0);
+    if (RT > 0 && !la && wave == (t & 3)) breg[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, r0 * (p.Rp * 2) + b_src, 0, 0);
+  };
+  auto lstore = [&](int t) {
+    const int slot = t % P;
+    char* const dst = Wr + (t % NS) * WSTAGE;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<u32x4*>(dst + w_dst[i]) = wreg[slot][i];
+    if (RT > 0 && t >= RT && wave == (t & 3)) *reinterpret_cast<u32x4*>(dst + WTILE + lane * 16) = breg[slot];
+  };
+  const int w_rd = n * (C * 2);                               // this lane's row of a tile image; chunk (4 ks + g) ^ n
+  bf16x8 wf[2][KSTEPS];
+  auto lread = [&](int t, int ks) {
+    wf[t & 1][ks] = *reinterpret_cast<const bf16x8*>(Wr + (t % NS) * WSTAGE + w_rd + (((4 * ks + g) ^ n) * 16));
+  };
+#pragma unroll
+  for (int t = 0; t < P; ++t) gload(t);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- LayerNorm statistics of this lane's token (16 w + n) from the producer's partials; s_n | c_n of the head's columns ----
+  float mean = 0.f, rstd = 0.f;
+  if (live) {
+    mean = ln_a * (1.f / C);
+    rstd = rsqrtf(fmaxf(ln_q * (1.f / C) - mean * mean, 0.f) + p.eps);
+  }
+  if (tid < 3 * D) { sn_l[tid] = sn_v; cn_l[tid] = cn_v; }
+  B64_STAMP(1)
+  lstore(0);
+  if (P < NTILES) gload(P);
+  lstore(1);
+  if (P + 1 < NTILES) gload(P + 1);
+  // raw barriers throughout: __syncthreads()' fence would drain the weight loads in flight (vmcnt(0)); the LDS writes are covered
+  // by the explicit lgkmcnt(0)
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  B64_STAMP(2)
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) lread(0, ks);
+  B64_STAMP(3)
+
+  bf16x8 tf = {0, 0, 0, 0, 0, 0, 0, 0};                      // T'' as the B operand of the LoRA k-step: slots = ranks {4g+j | 16+4g+j}
+  bf16x8 qf[DKS];                                            // Q of token n as the B operand of S^T = K Q^T: slots = dims {32 ks + 4g+j | + 16}
+#pragma unroll
+  for (int ks = 0; ks < DKS; ++ks) qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  const float irs = rstd != 0.f ? 1.f / rstd : 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NTILES; ++t) {
+    // stage t % NS holds tile t and its fragments are in wf[t & 1] (read during iteration t - 1); stage (t + 1) % NS holds tile t + 1
+    // (all waves' parts, barrier passed); stage (t + 2) % NS was last read in iteration t - 2
+    if (t + 2 < NTILES) {
+      lstore(t + 2);
+      if (t + 2 + P < NTILES) gload(t + 2 + P);
+    }
+    // with one wave per SIMD only this wave's own instruction stream can fill the 12 idle issue cycles behind each MFMA: the
+    // fragment reads of tile t + 1 are interleaved with the MFMAs of tile t
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks += 2) {                   // D[tile row 4 g + j][token n]
+      if (t + 1 < NTILES) { lread(t + 1, ks); lread(t + 1, ks + 1); }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t & 1][ks], xf[ks], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t & 1][ks + 1], xf[ks + 1], acc2, 0, 0, 0);
+    }
+    acc += acc2;
+    const char* Wb = Wr + (t % NS) * WSTAGE;
+    if (t < RT) {
+      // LoRA-A tile: T'' = T - mean sA + cA / rstd  (the epilogue's rstd (acc - mean s) + c then also fixes the LoRA term)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tf[4 * t + j] = (bf16)(acc[j] - mean * sa[t < RT ? t : 0][j] + ca[t < RT ? t : 0][j] * irs);
+    } else {
+      if (RT > 0) {
+        // LoRA: one more K = 32 step, A = the pre-scaled B rows of this tile with the same k-slot order
+        const char* brow = Wb + WTILE + n * 64 + g * 8;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(brow);
+        const bf16x4 hi = (RT > 1) ? *reinterpret_cast<const bf16x4*>(brow + 32) : bf16x4{0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), tf, acc, 0, 0, 0);
+      }
+      const int j0 = t - RT, sec = j0 / DTL, jj = j0 - sec * DTL;
+      const f32x4 sn = *reinterpret_cast<const f32x4*>(sn_l + sec * D + 16 * jj + 4 * g), cn = *reinterpret_cast<const f32x4*>(cn_l + sec * D + 16 * jj + 4 * g);
+      bf16x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = live ? (bf16)(rstd * (acc[j] - mean * sn[j]) + cn[j]) : (bf16)0.f;   // tokens >= N: K | V^T rows exactly zero
+      const int dcol = 16 * jj + 4 * g;                       // head-dim index of y[0]
+      if (sec == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qf[jj >> 1][(jj & 1) * 4 + j] = y[j];
+      } else if (sec == 1) {
+        *reinterpret_cast<bf16x4*>(Ks + tok * KSTR + dcol * 2) = y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16*>(Vt + (dcol + j) * VSTR + tok * 2) = y[j];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    B64_STAMP(4 + t)
+  }
+
+  // ---- attention over the head's 64 tokens; this wave's queries = its tokens ----
+  f32x4 s[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < DKS; ++ks) {
+      const char* krow = Ks + (16 * kt + n) * KSTR + (32 * ks + 4 * g) * 2;       // K[key 16 kt + n][dims 32 ks + 4 g .. | + 16 ..]
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(krow);
+      const bf16x4 hi = (32 * ks + 16 < D) ? *reinterpret_cast<const bf16x4*>(krow + 32) : bf16x4{0, 0, 0, 0};
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), qf[ks], s[kt], 0, 0, 0);   // S^T[key 16 kt + 4 g + j][query n]
+    }
+  }
+  B64_STAMP(21)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (16 * kt + 4 * g + j >= N) s[kt][j] = -INFINITY;
+      mx = fmaxf(mx, s[kt][j]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float l = 0.f;
+  bf16x8 pf[2];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16 pb = (bf16)__builtin_amdgcn_exp2f(s[kt][j] - mx);
+      l += (float)pb;                                         // the normaliser sums the SAME rounded values that multiply V
+      pf[kt >> 1][(kt & 1) * 4 + j] = pb;
+    }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  B64_STAMP(22)
+  // (the MFMAs run with every lane active -- a V^T row of the A operand lives in lane n whether or not query n is live; only
+  //  the store is guarded)
+  bf16* orow = p.out + (row0 + tok) * C + head * D;
+#pragma unroll
+  for (int t = 0; t < DTL; ++t) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const char* vrow = Vt + (16 * t + n) * VSTR + (32 * kk + 4 * g) * 2;      // V^T[16 t + n][keys 32 kk + 4 g .. | + 16 ..]
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf[kk], o, 0, 0, 0);
+    }
+    const bf16x4 ov = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
+    if (live) *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = ov;   // O^T[d 16 t + 4 g + j][query n]
+  }
+  B64_STAMP(23)
+#endif
+}
+
+template <int C, int D, int RT>
+int launch_blk64(const Blk64Args& a, int B, hipStream_t st) {
+  constexpr int LDS = 3 * (16 * C * 2 + 1024) + 64 * (D * 2 + 16) + D * (64 * 2 + 8) + 2 * 3 * D * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = attn_block64_kernel<C, D, RT>;
+  static unsigned long long attr_done = 0;
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), LDS, &attr_done, "attn_block64")) return rc;
+  hipLaunchKernelGGL(kern, dim3(a.H, B), dim3(256), LDS, st, a);
+  return aldm_launch_status("attn_block64");
+}
+
+unsigned long long* g_b64_diag = nullptr;
+
+
+}  // namespace
+
+// debugging hook (tools/debug_b64.py), not part of the drop-in boundary: 24 x u64 device buffer for in-kernel time stamps
+extern "C" void aldm_attn_block64_set_diag(void* buf) { g_b64_diag = (unsigned long long*)buf; }
+
+extern "C" int aldm_attn_block64(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+                                 const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used,
+                                 const float* ln_sa, const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out,
+                                 void* stream) {
+  ALDM_CHECK_ARG(x && ln_parts && w && bias && ln_s && out, "attn_block64: null pointer");
+  ALDM_CHECK_ARG(B > 0 && N > 0 && N <= 64 && ln_nparts > 0 && ln_nparts <= 16, "attn_block64: 1 <= N <= 64 tokens per sample, 1 <= ln_nparts <= 16");
+  ALDM_CHECK_ARG(Rp == 0 || (Rp % 16 == 0 && ranks_used > 0 && ranks_used <= 32 && ranks_used <= Rp && lora_a && lora_b && ln_sa && ln_ca),
+                 "attn_block64: LoRA needs Rp %% 16 == 0, 1 <= ranks_used <= min(32, Rp) and lora_a / lora_b / ln_sa / ln_ca");
+  ALDM_CHECK_ARG(H == 8 && d == 80 && Kpad == 640, "attn_block64: built for C = 640 = 8 heads x 80 (the UNet's 64-token level); got H %d d %d Kpad %d", H, d, Kpad);
+  Blk64Args a{(const bf16*)x, ln_parts, (const bf16*)w, bias, ln_s, (const bf16*)lora_a, (const bf16*)lora_b, ln_sa, ln_ca, (bf16*)out,
+              ln_nparts, Kpad, Rp, N, H, ln_eps, g_b64_diag};
+  hipStream_t st = (hipStream_t)stream;
+  if (Rp == 0) return launch_blk64<640, 80, 0>(a, B, st);
+  if (ranks_used <= 16) return launch_blk64<640, 80, 1>(a, B, st);   // rank-4 q | k | v = 12 rows: one LoRA-A tile, the zero rows skipped
+  return launch_blk64<640, 80, 2>(a, B, st);
+}

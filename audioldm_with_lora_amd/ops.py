@@ -157,6 +157,7 @@ def attach_lora(pw: PackedW, parts):
         b[row0:row0 + nrows, col:col + r] = (Bm.detach().float() * s).to(torch.bfloat16)
         col += r
     pw.lora_a, pw.lora_b, pw.Rp = a.contiguous(), b.contiguous(), rp
+    pw.ranks_used = col
     if ln is not None:
         pw.ln_sa, pw.ln_ca = sa, ca
     return pw
@@ -718,6 +719,29 @@ def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False, prescaled=Fa
     check(_launch(f"attention_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention(
         q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),
         _p(out), Cc, _stream())), "aldm_attention")
+    return out
+
+
+def attn_block64_ok(pw, N, H, d, ln_parts):
+    """Can the (sample, head)-fused projection + attention launch take this module?  (C = 640 = 8 x 80, N <= 64, LayerNorm folded
+    with the producer's statistics at hand, combined LoRA rank <= 32.)"""
+    return (N <= 64 and H == 8 and d == 80 and pw.N == 1920 and pw.Kpad == 640 and pw.ln_s is not None and ln_parts is not None
+            and (pw.Rp == 0 or getattr(pw, "ranks_used", 99) <= 32))
+
+
+def attn_block64(x2d, pw, ln_parts, B, N, H, d):
+    """x2d [B*N, C] raw hidden state -> attention output [B*N, C]: LayerNorm-folded QKV projection with LoRA + 64-token attention,
+    one launch (aldm_attn_block64)."""
+    _require_gpu(x2d)
+    Cc = H * d
+    assert x2d.dtype == torch.bfloat16 and x2d.is_contiguous() and tuple(x2d.shape) == (B * N, Cc)
+    assert ln_parts.dtype == torch.float32 and ln_parts.is_contiguous() and ln_parts.shape[0] == B * N
+    out = torch.empty(B * N, Cc, dtype=torch.bfloat16, device=x2d.device)
+    fl = B * (6.0 * N * Cc * Cc + 4.0 * N * N * Cc + (12.0 * N * Cc * getattr(pw, "ranks_used", 0) if pw.Rp else 0.0))
+    check(_launch(f"attn_block64_d{d}_n{N}", fl, 2.0 * (2 * B * N * Cc + 3 * Cc * Cc), lambda: _lib.load().aldm_attn_block64(
+        _p(x2d), _p(ln_parts), ln_parts.shape[1], _p(pw.w), pw.Kpad, _p(pw.bias), _p(pw.ln_s), _p(pw.lora_a), _p(pw.lora_b), pw.Rp,
+        getattr(pw, "ranks_used", 0) if pw.Rp else 0, _p(pw.ln_sa), _p(pw.ln_ca), pw.ln_eps, B, N, H, d, _p(out), _stream())),
+        "aldm_attn_block64")
     return out
 
 

@@ -272,9 +272,15 @@ def run_attention(P, hn, h_res, B, N, fp8=False, ln_parts=None, rowstats=False):
     producer of h); returns h_res + to_out(attention(q, k, v)) with LoRA fused in both GEMMs -- and, with rowstats, the row
     statistics of that sum for the LayerNorm that follows."""
     C = P.c
+    ops.SITE = f"attn C{C} N{N}"                      # bench.py prices these launches as ONE fused-LoRA attention module (K1)
+    if not fp8 and ops.attn_block64_ok(P.qkv, N, P.heads, P.d, ln_parts):
+        # the 64-token level: projection (+ LoRA, folded LayerNorm) and attention of a (sample, head) in ONE launch; Q | K | V stay in LDS
+        a = ops.attn_block64(hn, P.qkv, ln_parts, B, N, P.heads, P.d)
+        y = ops.linear(a, P.out, res=h_res, rowstats=rowstats)
+        ops.SITE = None
+        return y
     npad = (N + 7) // 8 * 8
     vt = torch.empty(B, C, npad, dtype=torch.bfloat16, device=hn.device)
-    ops.SITE = f"attn C{C} N{N}"                      # bench.py prices these three launches as ONE fused-LoRA attention module (K1)
     qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad, ln_parts=ln_parts)
     a = ops.attention(qk.view(B * N, 2 * C), vt, B, N, P.heads, P.d, fp8=fp8, prescaled=True)
     y = ops.linear(a, P.out, res=h_res, rowstats=rowstats)

@@ -166,11 +166,12 @@ def k1_sites(rows, ubatch, rank_lora):
         if not site:
             continue
         s = sites.setdefault(site, dict(modules=0, us=0.0, ev_us=0.0, parts={}))
-        part = "attention" if label.startswith("attention") else ("qkv_lora" if "_vt" in label else "out_proj_lora")
+        part = ("qkv_lora+attention" if label.startswith("attn_block64") else "attention" if label.startswith("attention")
+                else ("qkv_lora" if "_vt" in label else "out_proj_lora"))
         s["parts"][part] = s["parts"].get(part, 0.0) + us
         s["us"] += us
         s["ev_us"] += ev_us
-        s["modules"] += 1 if part == "attention" else 0
+        s["modules"] += 1 if "attention" in part else 0
     out = []
     for site, s in sorted(sites.items()):
         C, N = int(site.split()[1][1:]), int(site.split()[2][1:])

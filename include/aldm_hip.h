@@ -192,6 +192,17 @@ int aldm_attention_prescaled(const void* q, int ldq, const void* k, int ldk, con
 int aldm_attention_wide(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_batch_stride,
                         int B, int N, int d, void* out, int out_ld, void* stream);
 
+/* The front half of the fused-LoRA attention module as ONE launch, for the UNet's 64-token level (C = 640 = 8 heads x 80,
+   N <= 64 tokens per sample): LayerNorm (folded; statistics from the producer's ln_parts, see aldm_igemm_t) -> to_q | to_k | to_v
+   with the LoRA side channel -> softmax(Q K^T) V per (sample, head) workgroup; Q | K | V stay in LDS.  Operands exactly as
+   aldm_igemm takes them for the folded QKV GEMM: w [3C][Kpad] (q rows pre-scaled by d^-0.5 log2 e), bias = c_n, ln_s, lora_a
+   [Rp][Kpad], lora_b [3C][Rp] (pre-scaled), ln_sa / ln_ca [Rp]; ranks_used = rows of lora_a that are not padding.
+   out [B*N][C] bf16 = the heads' attention outputs, ready for to_out.  diffusers Attention under
+   [REF script/train/train_audioldm_lora.py:539-546] / [REF script/inference/generate_audio.py:47-52]. */
+int aldm_attn_block64(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+                      const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used, const float* ln_sa,
+                      const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out, void* stream);
+
 /* Same, additionally writing the log2-domain log-sum-exp of the scaled scores, lse [B][H][N] fp32 (training). */
 /* Same core with a per-batch-item key count kv_len[B] (int32, device): keys >= kv_len[b] are excluded exactly as an
    additive -inf attention_mask excludes right-padded tokens, and the key loop stops at the last valid tile.  Query
