@@ -55,6 +55,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int C, int D, int RT /* LoRA rank tiles of 16: 0, 1 or 2 */>
 __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  aldm_touch_kernargs<sizeof(Blk64Args)>();
   constexpr int NTOK = 64, CPR = C / 8;                      // 16-byte chunks per row
   constexpr int KSTEPS = C / 32;
   constexpr int DTL = D / 16;                                 // 16-column tiles per q / k / v section

@@ -244,3 +244,25 @@ extern "C" int aldm_adamw_flat(float* p, const float* g, float* m, float* v, lon
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
   return aldm_launch_status("adamw_flat");
 }
+
+// ---- debugging hook (tools/probe_latency.py), not part of the drop-in boundary: what does a kernel's FIRST memory access cost? ----
+// One wave: stamp, dependent loads from up to four addresses (each waited for), stamp after each.  out[0..4] = s_memtime values.
+__global__ void latency_probe_kernel(const int* a, const int* b, const int* c, const int* d, unsigned long long* out, int* sink) {
+  unsigned long long t0, t1, t2, t3, t4;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  int va = __builtin_nontemporal_load(a + threadIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(va) : "memory");
+  int vb = __builtin_nontemporal_load(b + threadIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) : "v"(vb) : "memory");
+  int vc = __builtin_nontemporal_load(c + threadIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3) : "v"(vc) : "memory");
+  int vd = __builtin_nontemporal_load(d + threadIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t4) : "v"(vd) : "memory");
+  if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; out[2] = t2; out[3] = t3; out[4] = t4; }
+  if (va + vb + vc + vd == 0x7fffffff) sink[0] = 1;
+}
+extern "C" int aldm_probe_latency(const void* a, const void* b, const void* c, const void* d, void* out, void* sink, void* stream) {
+  hipLaunchKernelGGL(latency_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)a, (const int*)b, (const int*)c, (const int*)d,
+                     (unsigned long long*)out, (int*)sink);
+  return aldm_launch_status("latency_probe");
+}

@@ -616,6 +616,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
 // ---- main kernel ------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int RP, bool VT>
 __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
+  aldm_touch_kernargs<sizeof(IgemmDev)>();
   static_assert(WM * WN == 4, "4 waves");
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr int BROWS = BN + RP;
@@ -858,6 +859,7 @@ template <int BM, int BN, int WM, int WN, int RP, bool VT, int S, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev p) {
   constexpr bool LEAN = EPI == 1 || EPI == 4;
 #if defined(__HIP_DEVICE_COMPILE__)
+  aldm_touch_kernargs<sizeof(IgemmDev)>();
 #ifdef ALDM_DIAG
   unsigned long long dg_t_entry; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_entry) :: "memory");
 #endif
@@ -1221,6 +1223,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
 
 // ---- split-K reduce + epilogue ----------------------------------------------------------------
 static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev p) {
+  aldm_touch_kernargs<sizeof(IgemmDev)>();
   const int ncols = p.geglu ? (p.N >> 1) : p.N;
   const int nq = ncols >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -26,6 +26,7 @@ namespace aldm_igemm_detail {
 template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, int EPI /* 0 full, 1 lean, 4 lean + statistics */>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  aldm_touch_kernargs<sizeof(IgemmDev)>();
   static_assert(WM * WN == 8, "8 waves");
   constexpr int NT = 512, RPP = NT / 8;                 // 64 tile rows per whole-workgroup DMA pass
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;

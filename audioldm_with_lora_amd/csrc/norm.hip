@@ -93,6 +93,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
                                                                    bf16* __restrict__ y, AldmDiv dqpp) {
+  aldm_touch_kernargs<96>();                // 84 bytes of explicit arguments: both lines in one round (common.h)
   __shared__ float red[GN_THREADS / 64];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
                                                                         const float* __restrict__ gamma,
                                                                         const float* __restrict__ beta, int act,
                                                                         bf16* __restrict__ y, AldmDiv dqpp) {
+  aldm_touch_kernargs<160>();               // 148 bytes of explicit arguments: all three lines in one round (common.h)
   // C = channels of the partial tiles (first source); C2 more channels come as plain bf16 from x2 (torch.cat([h, skip]) in
   // front of an up-block ResnetBlock2D's norm1).  A group lies wholly in one source (host-checked: C % group width == 0).
   __shared__ float red[GN_THREADS / 64];
