@@ -114,6 +114,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.la_bytes = (unsigned)lb;
     d.lb_bytes = (unsigned)(2ull * p->Cout * p->Rp);
     d.fd_ohw = make_fastdiv((unsigned)d.OHW); d.fd_ow = make_fastdiv((unsigned)d.OW); d.fd_halo = make_fastdiv((unsigned)d.OW + 2u);
+    d.fd_ctot = make_fastdiv((unsigned)d.Ctot); d.fd_kw = make_fastdiv((unsigned)d.KW);
     d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
     d.rowstat = p->rowstat_out; d.ln_parts = p->ln_parts; d.ln_np = p->ln_nparts;
     d.qstat = p->qstat_out; d.qtile = -1;

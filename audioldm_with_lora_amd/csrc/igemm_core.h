@@ -59,6 +59,8 @@ struct IgemmDev {
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
   unsigned long long* diag;   // diagnostic builds only
   FastDiv fd_ohw, fd_ow, fd_halo;   // fd_halo: / (OW + 2), halo kernel only
+  FastDiv fd_tiles_n, fd_ctot, fd_kw;   // the pipe kernel's prologue: tile index / tiles_n, K cursor / Ctot, tap / KW (scalar divisions
+                                        // by a run-time value are ~30 VALU instructions each, on the path to the first DMA)
   const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;   // LayerNorm folded into the GEMM (see below)
   const bf16* x3; const bf16* x4; int Cin3, Cin4, C3tot; unsigned x3_bytes, x4_bytes;   // fused 1x1 second-source segment (shortcut)
   float* qstat; int qtile;    // GroupNorm hand-over: per (M-tile, image slot, 4-channel quad) partial (sum, sum of squares); qtile >= 0 overrides m0 / BM
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int tile_m = fdiv(blockIdx.x, p.fd_tiles_n), tile_n = blockIdx.x - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.z;
   const int kt0 = split * p.kt_per_split;
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tile_m = wgid / p.tiles_n, tile_n = wgid - tile_m * p.tiles_n;
+  const int tile_m = fdiv(wgid, p.fd_tiles_n), tile_n = wgid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.z;
   const int kt0 = split * p.kt_per_split;
@@ -935,9 +937,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
     if (k >= kmain && p.C3tot > 0) {
       s_kh = p.KH; s_kw = 0; s_c0 = k - kmain;
     } else {
-      const int tap = k / p.Ctot;
+      const int tap = fdiv(k, p.fd_ctot);
       s_c0 = k - tap * p.Ctot;
-      s_kh = tap / p.KW;
+      s_kh = fdiv(tap, p.fd_kw);
       s_kw = tap - s_kh * p.KW;
     }
   }
@@ -1298,6 +1300,7 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   }
   IgemmDev dd = d;
   dd.tiles_n = cdiv(d.N, BN);
+  dd.fd_tiles_n = make_fastdiv((unsigned)dd.tiles_n);
   dim3 grid(cdiv(d.M, BM) * dd.tiles_n, 1, d.splits);
   hipLaunchKernelGGL(kern, grid, dim3(S == 0 ? THREADS : 64 * WM * WN), lds, st, dd);
   return aldm_launch_status("igemm");

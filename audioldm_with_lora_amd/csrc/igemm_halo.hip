@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   const int HW2 = W + 2;
   const int rows_pt = BM / W;                           // image rows per tile (host guarantees BM % W == 0)
   const int tpi = (H + rows_pt - 1) / rows_pt;          // tiles per image
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int tile_m = fdiv(blockIdx.x, p.fd_tiles_n), tile_n = blockIdx.x - tile_m * p.tiles_n;
   const int img = tile_m / tpi, ty0 = (tile_m - img * tpi) * rows_pt;
   const int m0 = img * p.OHW + ty0 * W, n0 = tile_n * BN;
   const int halo_rows = (rows_pt + 2) * HW2;
@@ -204,6 +204,7 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   }
   IgemmDev dd = d;
   dd.tiles_n = cdiv(d.N, BN);
+  dd.fd_tiles_n = make_fastdiv((unsigned)dd.tiles_n);
   dd.fd_halo = make_fastdiv((unsigned)(d.OW + 2));
   const int tpi = cdiv(d.OH, rows_pt);
   dim3 grid(d.B * tpi * dd.tiles_n, 1, 1);
