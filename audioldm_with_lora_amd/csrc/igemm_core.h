@@ -1082,6 +1082,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   //      freed by tile kt-1 -> MFMAs on tile kt.  Tiles past the end are dummy zero-page loads so that the
   //      vmcnt immediate stays constant.
   char* const LBs = smem + S * STAGE;     // [BN][128 B] image of the pre-scaled LoRA-B tile (RP > 0 only)
+#ifdef ALDM_DIAG
+  unsigned long long dg_t_pro0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_pro0) : "v"(a_pix0[0] + a_ih0[0] + a_iw0[0]), "v"(b_off[0]), "s"(s_kh + s_kw + s_c0) : "memory");
+#endif
   if (RP > 0) {
     // issued FIRST: vmcnt retires in order, so the first counted wait of the ring also covers these
     const __amdgpu_buffer_rsrc_t rs_lb = make_rsrc(p.lora_b, p.lb_bytes);
@@ -1095,6 +1098,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(kt0 + s, s);
 #ifdef ALDM_DIAG   // diagnostic build only (tools/diag_igemm.py): per-wave cycle split of the main loop
+  unsigned long long dg_t_pro1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_pro1) :: "memory");
   unsigned long long dg_wait = 0, dg_bar = 0, dg_issue = 0, dg_mma = 0;
 #define ALDM_STAMP(var) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; }
 #endif
@@ -1217,7 +1221,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
     o[0] = dg_wait; o[1] = dg_bar; o[2] = dg_issue; o[3] = dg_mma;
     o[4] = dg_t_loop_end - dg_t_entry - (dg_wait + dg_bar + dg_issue + dg_mma);   // prologue (everything before / around the loop)
     o[5] = dg_t_end - dg_t_loop_end;                                               // LoRA tail + epilogue incl. store drain
-    o[6] = dg_t_entry; o[7] = dg_t_end;
+    o[6] = dg_t_pro0 - dg_t_entry;   // kernel entry -> ready to fill the ring (kernel arguments, descriptors, index arithmetic)
+    o[7] = dg_t_pro1 - dg_t_pro0;    // issue of the first D ring stages (+ the LoRA-B tile)
   }
 #endif
 #endif

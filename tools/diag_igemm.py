@@ -45,10 +45,10 @@ def main():
         tot = d.sum(-1)
         share = (d / tot.unsqueeze(-1)).mean((0, 1))
         pro, epi = raw[:, :, 4].double().mean(), raw[:, :, 5].double().mean()
-        span = (raw[:, :, 7].max() - raw[:, :, 6].min()).item()
+        setup, fill = raw[:, :, 6].double().mean(), raw[:, :, 7].double().mean()
         print(f"{name:18s} tile {bm}x{bn} ring {ring}: {tot.mean() / nkt:6.0f} cycles/K-tile/wave | wait_vmcnt {share[0]:.2f} "
-              f"barrier {share[1]:.2f} dma_issue {share[2]:.2f} mma+lds {share[3]:.2f} || per wave: prologue {pro:.0f}  loop {tot.mean():.0f}  "
-              f"tail+epilogue {epi:.0f} cycles; first-entry -> last-exit {span} cycles", flush=True)
+              f"barrier {share[1]:.2f} dma_issue {share[2]:.2f} mma+lds {share[3]:.2f} || per wave: entry->ring fill {setup:.0f} + fill issue {fill:.0f} "
+              f"(prologue incl. stamp overhead {pro:.0f})  loop {tot.mean():.0f}  tail+epilogue {epi:.0f} cycles", flush=True)
 
     # the fused QKV GEMM of an attention module: LoRA side channel (Rp = 32), V^T transposed store, folded LayerNorm
     for (name, B, N, Cc, ring) in (("QKV+LoRA+Vt C256", 8, 1000, 256, 2), ("QKV+LoRA+Vt C384", 8, 252, 384, 2), ("out+LoRA C256", 8, 1000, 256, 3)):
@@ -85,16 +85,7 @@ def main():
         torch.cuda.synchronize()
         bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64)}[tile]
         nwg = math.ceil(B * H * W / bm) * math.ceil(co / bn)
-        raw = ws[: nwg * 4 * 8 * 2].view(torch.int64).view(nwg, 4, 8)
-        d = raw[:, :, :4].double()
-        tot = d.sum(-1)
-        share = (d / tot.unsqueeze(-1)).mean((0, 1))
-        nkt = k * k * ci // 64
-        pro, epi = raw[:, :, 4].double().mean(), raw[:, :, 5].double().mean()
-        span = (raw[:, :, 7].max() - raw[:, :, 6].min()).item()
-        print(f"{name:18s} tile {bm}x{bn} ring {ring}: {tot.mean() / nkt:6.0f} cycles/K-tile/wave | wait_vmcnt {share[0]:.2f} "
-              f"barrier {share[1]:.2f} dma_issue {share[2]:.2f} mma+lds {share[3]:.2f} || per wave: prologue {pro:.0f}  loop {tot.mean():.0f}  "
-              f"tail+epilogue {epi:.0f} cycles; first-entry -> last-exit {span} cycles")
+        report(name, nwg, k * k * ci // 64, bm, bn, ring)
 
 
 if __name__ == "__main__":
