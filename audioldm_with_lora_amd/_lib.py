@@ -52,6 +52,26 @@ class IgemmArgs(C.Structure):
     ]
 
 
+class PgemmArgs(C.Structure):
+    """Mirror of aldm_pgemm_t (include/aldm_hip.h) -- field order and types must match exactly."""
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("bias", C.c_void_p),
+        ("ln_s", C.c_void_p), ("ln_sa", C.c_void_p), ("ln_ca", C.c_void_p), ("ln_eps", C.c_float),
+        ("ln_parts", C.c_void_p), ("ln_nparts", C.c_int),
+        ("lora_a", C.c_void_p), ("lora_b", C.c_void_p),
+        ("Rp", C.c_int), ("ranks_used", C.c_int),
+        ("geglu", C.c_int),
+        ("res", C.c_void_p),
+        ("out", C.c_void_p), ("out_ld", C.c_int),
+        ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_ld", C.c_int), ("vt_batch_stride", C.c_longlong), ("OHW", C.c_int),
+        ("rowstat_out", C.c_void_p),
+        ("mi", C.c_int), ("nt", C.c_int), ("tiles_per_range", C.c_int),
+        ("max_ranges", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes): every symbol include/aldm_hip.h declares
 PROTOTYPES = {
     "aldm_version": (C.c_char_p, []),
@@ -59,6 +79,9 @@ PROTOTYPES = {
     "aldm_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
     "aldm_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmArgs)]),
     "aldm_igemm_effective_splits": (C.c_int, [C.POINTER(IgemmArgs)]),
+    "aldm_pgemm_supported": (C.c_int, [C.c_int]),
+    "aldm_pgemm_plan": (C.c_int, [C.POINTER(PgemmArgs)]),
+    "aldm_pgemm": (C.c_int, [C.POINTER(PgemmArgs), C.c_void_p]),
     "aldm_groupnorm_partials": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -572,6 +572,7 @@ extern "C" int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, i
   const int C = C1 + C2;
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % (C / groups) == 0 && C1 % 8 == 0 && C2 % 8 == 0,
                  "groupnorm_apply: group width %d must be a multiple of 4 that divides C1 = %d; C1, C2 multiples of 8", C / groups, C1);
+  ALDM_CHECK_ARG(C / 8 <= 256, "groupnorm_apply: at most 2048 channels (a workgroup walks %d 16-byte units per pixel with 256 threads)", C / 8);
   ALDM_CHECK_ARG((tpi > 0 || (bm > 0 && bm <= HW)) && (C2 == 0 || tpi2 > 0 || (bm2 > 0 && bm2 <= HW)),
                  "groupnorm_apply: an M-tile of the producer may span at most two images (tile rows <= H*W)");
   int lpg = 1;

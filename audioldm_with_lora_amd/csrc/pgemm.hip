@@ -1,0 +1,610 @@
+// Projection GEMM for the transformer blocks: y[M][N] = x[M][K] W[N][K]^T with K = 256 / 384 / 640 at compile time.
+//
+// Serves the linear layers of BasicTransformerBlock / Transformer2DModel inside UNet2DConditionModel.forward
+// [REF script/train/train_audioldm_lora.py:539-546] / the DDIM loop [REF script/inference/generate_audio.py:47-52]:
+//   proj_in (1x1 conv), to_q | to_k | to_v (one GEMM, LayerNorm folded, peft LoRA side channel [REF train:378-385], V stored
+//   token-major), to_out.0 (+ LoRA + bias + residual), the GEGLU projection (LayerNorm folded).
+// These ran on the implicit-GEMM CONVOLUTION kernel (igemm_core.h): tap cursor, descriptor range logic, magic divisions, an
+// LDS transposition in the epilogue -- 674 VALU instructions per wave against 52 MFMAs (profiles/r02d_pmc_sq.json).  With K this
+// short the structure is turned around:
+//   * a wave owns 16 MI rows of x for the WHOLE K: the fragments go global -> registers once (B operand of the "swapped"
+//     v_mfma_f32_16x16x32_bf16, weights = A operand) and never touch LDS;
+//   * the workgroup (4 waves, 64 MI rows) walks over its range of output columns in N-tiles of NT columns: a tile = NT weight
+//     rows x full K, streamed global -> LDS by LDS-DMA (buffer_load ... lds) into a 3-stage ring, XOR-swizzled on the SOURCE
+//     side so that every ds_read_b128 fragment read is conflict-free; one counted s_waitcnt + one s_barrier per N-tile;
+//   * no K loop state at all, no divisions except the V^T (batch, token) split, and the accumulators are stored STRAIGHT from
+//     registers: the rows of a weight tile are handed to the MFMA in a permuted order (lane (c, q) reads row
+//     32 t + 8 (r >> 2) + 4 s + (r & 3) for sub-tile 2 t + s), so that a lane ends up with 8 CONSECUTIVE output columns of one row
+//     -> one 16-byte store, no LDS transposition.  The V^T tiles use the un-swapped operand order and the same trick on the row
+//     side (a lane owns 8 consecutive tokens of one channel).
+//   * LoRA: T = x A^T from LoRA-A fragments loaded straight into registers (16 ranks per MFMA tile), rounded to bf16 in
+//     registers and applied to every N-tile as one more K = 32 step against the pre-scaled B rows (k order = accumulator row
+//     permutation, reproduced by two 8-byte reads of B);
+//   * LayerNorm folded (statistics from the producer's rowstat table), LayerNorm statistics for the NEXT consumer, bias and
+//     residual (residual tile by LDS-DMA, wave-private) in the epilogue.
+#include "igemm_core.h"   // make_rsrc / lds_ptr_t / wait_vmcnt / FastDiv
+
+namespace {
+
+using aldm_igemm_detail::FastDiv;
+using aldm_igemm_detail::fdiv;
+using aldm_igemm_detail::lds_ptr_t;
+using aldm_igemm_detail::make_fastdiv;
+using aldm_igemm_detail::wait_vmcnt;
+
+struct PgArgs {
+  const bf16* x; const bf16* w; const bf16* lora_a; const bf16* lora_b;
+  const float* bias; const float* ln_s; const float* ln_sa; const float* ln_ca; const float* ln_parts;
+  const bf16* res; bf16* out; bf16* vt; float* rowstat;
+  int M, N, Rp, ln_np, out_ld;
+  int vt_col0, vt_ld, OHW, vt_vec;        // vt_vec: tokens per V^T store (8, 4 or 1)
+  long long vt_bs;
+  FastDiv fd_ohw, fd_nr;
+  int nranges, tpr;                        // column ranges per row block; N-tiles per range
+  float ln_eps;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+enum { PG_LN = 1, PG_RES = 2, PG_RSTAT = 4 };
+enum { EPI_STD = 0, EPI_VT = 1, EPI_GEGLU = 2 };
+
+__device__ __forceinline__ int pg_hsw(int R) { return ((R & 3) | (((R >> 3) & 1) << 2)) << 1; }   // chunk XOR of weight row R
+
+template <int K, int NT, int MI, int RT, int EPI, int FL>
+__global__ __launch_bounds__(256) void pgemm_kernel(const PgArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  aldm_touch_kernargs<sizeof(PgArgs)>();
+  constexpr bool LN = (FL & PG_LN) != 0, RES = (FL & PG_RES) != 0, RSTAT = (FL & PG_RSTAT) != 0;
+  constexpr int BM = 64 * MI, KS = K / 32, CPR = K / 8, NJ = NT / 16;
+  constexpr int WT = NT * K * 2;                              // bytes of a weight tile
+  constexpr int PWW = WT / 1024 / 4;                          // its 1 KB DMA pieces per wave
+  constexpr int RB = RES ? BM * NT * 2 : 0;                   // residual tile (wave w: rows 16 MI w ..)
+  constexpr int PRW = RES ? (16 * MI * NT * 2) / 1024 : 0;
+  constexpr int STG = WT + RB, P = PWW + PRW;
+  constexpr int RCH = NT / 8;                                 // 16-byte chunks per residual row
+  static_assert(WT % 4096 == 0, "weight tile = whole DMA pieces per wave");
+  static_assert(!RES || (16 * MI * NT * 2) % 1024 == 0, "residual tile = whole DMA pieces per wave");
+  static_assert(EPI != EPI_GEGLU || NT == 64, "GEGLU tiles are 64 packed columns (16 value | 16 gate blocks)");
+  static_assert(NJ % 2 == 0, "column sub-tiles come in pairs");
+  static_assert(P < 64, "vmcnt immediate");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  int wgid;
+  {   // XCD-aware order (blocks b, b + 8, ... share an L2): the column ranges of one row block run on one XCD
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+  }
+  const int mblk = fdiv(wgid, p.fd_nr), nr = wgid - mblk * p.nranges;
+  const int T = p.tpr, BNW = T * NT;
+  const int m0 = mblk * BM, n_wg0 = nr * BNW;
+  const int mw0 = wave * 16 * MI;
+  const int SR = T < 3 ? T : 3;                                // ring stages in use
+  float* const stat = reinterpret_cast<float*>(smem + SR * STG);   // [2][BM]: mean, rstd
+  float* const cvec = stat + 2 * BM;                          // [2][BNW]: c_n (bias), s_n
+  char* const LB = reinterpret_cast<char*>(cvec + 2 * BNW);   // [BNW][Rp] bf16: the range's pre-scaled LoRA-B rows
+
+  const __amdgpu_buffer_rsrc_t rs_x = aldm_igemm_detail::make_rsrc(p.x, (unsigned)p.M * (unsigned)(K * 2));
+  const __amdgpu_buffer_rsrc_t rs_w = aldm_igemm_detail::make_rsrc(p.w, (unsigned)p.N * (unsigned)(K * 2));
+
+  // ---- x fragments of this wave's rows, straight into registers.  Lane (c, q) holds x[row rl(i, c)][32 ks + 8 q .. + 7] with
+  //      rl(i, c) = 4 MI (c >> 2) + 4 i + (c & 3): as the A operand of the un-swapped (V^T) product a lane then owns 4 MI
+  //      consecutive rows.  Rows >= M read as zeros through the descriptor's range check. ----
+  int mrow[MI];
+  bf16x8 xf[MI][KS];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    mrow[i] = m0 + mw0 + 4 * MI * (c >> 2) + 4 * i + (c & 3);
+    const int off = mrow[i] * (K * 2) + q * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[i][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + ks * 64, 0, 0));
+  }
+  // ---- LoRA-A fragments (A operand: lane (c, q) holds A[16 rt + c][32 ks + 8 q ..]) ----
+  bf16x8 af[RT > 0 ? RT : 1][RT > 0 ? KS : 1];
+  f32x4 sa[RT > 0 ? RT : 1], ca[RT > 0 ? RT : 1];
+  if constexpr (RT > 0) {
+    const __amdgpu_buffer_rsrc_t rs_a = aldm_igemm_detail::make_rsrc(p.lora_a, (unsigned)p.Rp * (unsigned)(K * 2));
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        af[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (16 * rt + c) * (K * 2) + q * 16 + ks * 64, 0, 0));
+      if constexpr (LN) {
+        sa[rt] = *reinterpret_cast<const f32x4*>(p.ln_sa + 16 * rt + 4 * q);
+        ca[rt] = *reinterpret_cast<const f32x4*>(p.ln_ca + 16 * rt + 4 * q);
+      }
+    }
+  }
+  // ---- LayerNorm statistics of this lane's rows from the producer's partial sums ----
+  float mean[MI], rstd[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
+  if constexpr (LN) {
+    float s1[MI], s2[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      s1[i] = s2[i] = 0.f;
+      if (mrow[i] < p.M) {
+        const float* pp = p.ln_parts + (long long)mrow[i] * (p.ln_np * 2);
+        for (int j = 0; j < p.ln_np; ++j) {
+          const float2 v2 = *reinterpret_cast<const float2*>(pp + 2 * j);
+          s1[i] += v2.x;
+          s2[i] += v2.y;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      mean[i] = s1[i] * (1.f / K);
+      rstd[i] = rsqrtf(fmaxf(s2[i] * (1.f / K) - mean[i] * mean[i], 0.f) + p.ln_eps);
+    }
+  }
+  // ---- column vectors of the range: c_n (bias; zeros when there is none) and s_n ----
+  float cv0[2] = {0.f, 0.f}, cv1[2] = {0.f, 0.f};             // BNW <= 512: two columns per thread
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int nn = tid + 256 * u;
+    if (nn < BNW) {
+      if (p.bias) cv0[u] = p.bias[n_wg0 + nn];
+      if constexpr (LN) cv1[u] = p.ln_s[n_wg0 + nn];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- the DMA streams.  Per-lane source offsets of this wave's pieces of a weight tile: physical chunk u of the linear LDS
+  //      image = (row R, chunk pc); it receives logical chunk pc ^ hsw(R) (both-sides-or-neither: the fragment reads apply the
+  //      same XOR). ----
+  unsigned w_off[PWW];
+#pragma unroll
+  for (int pp = 0; pp < PWW; ++pp) {
+    const int u = (wave * PWW + pp) * 64 + lane;
+    const int R = u / CPR, pc = u - R * CPR;
+    w_off[pp] = (unsigned)(R * (K * 2) + ((pc ^ pg_hsw(R)) * 16));
+  }
+  unsigned r_off[PRW > 0 ? PRW : 1];
+  __amdgpu_buffer_rsrc_t rs_r = rs_x;
+  if constexpr (RES) {
+    rs_r = aldm_igemm_detail::make_rsrc(p.res, (unsigned)p.M * (unsigned)(p.out_ld * 2));
+#pragma unroll
+    for (int pp = 0; pp < PRW; ++pp) {
+      const int u = pp * 64 + lane;                           // chunk of the wave's [16 MI][RCH] image
+      const int rl = u / RCH, pc = u - rl * RCH;
+      const int f = MI == 2 ? (((rl >> 1) & 1) | (((rl >> 3) & 3) << 1)) : ((rl >> 1) & 7);
+      r_off[pp] = (unsigned)((m0 + mw0 + rl) * (p.out_ld * 2) + ((pc ^ (f & (RCH - 1))) * 16));
+    }
+  }
+  auto issue = [&](int t) {                                   // N-tile t of the range -> stage t % 3
+    char* const sb = smem + (t % 3) * STG;
+    const int soff = (n_wg0 + t * NT) * (K * 2);
+#pragma unroll
+    for (int pp = 0; pp < PWW; ++pp)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sb + (wave * PWW + pp) * 1024), 16, w_off[pp], soff, 0, 0);
+    if constexpr (RES) {
+      const int roff = (n_wg0 + t * NT) * 2;
+#pragma unroll
+      for (int pp = 0; pp < PRW; ++pp)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_ptr_t)(sb + WT + (wave * PRW + pp) * 1024), 16, r_off[pp], roff, 0, 0);
+    }
+  };
+  if constexpr (RT > 0) {                                     // issued first: vmcnt retires in order, the first ring wait covers them
+    const __amdgpu_buffer_rsrc_t rs_lb = aldm_igemm_detail::make_rsrc(p.lora_b, (unsigned)p.N * (unsigned)(p.Rp * 2));
+    const int npc = (BNW * p.Rp * 2) >> 10;
+    for (int pc = wave; pc < npc; pc += 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lb, (lds_ptr_t)(LB + pc * 1024), 16, (unsigned)(n_wg0 * (p.Rp * 2) + pc * 1024 + lane * 16), 0, 0, 0);
+  }
+  issue(0);
+  if (T > 1) issue(1);
+
+  // ---- T = x A^T, corrected for the folded LayerNorm and rounded to bf16: the B operand of the LoRA k-step.
+  //      k slots {8 q + jj}: ranks {4 q + jj | 16 + 4 q + (jj - 4)} (the accumulator rows this lane holds) ----
+  bf16x8 tf[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) tf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (RT > 0) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const float irs = 1.f / rstd[i];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+          ta = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][ks], xf[i][ks], ta, 0, 0, 0);
+          tb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][ks + 1], xf[i][ks + 1], tb, 0, 0, 0);
+        }
+        ta += tb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = ta[e];
+          if constexpr (LN) v = v - mean[i] * sa[rt][e] + ca[rt][e] * irs;
+          tf[i][4 * rt + e] = (bf16)v;
+        }
+      }
+    }
+  }
+  // ---- park the small operands in LDS (read after the first barrier) ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int nn = tid + 256 * u;
+    if (nn < BNW) { cvec[nn] = cv0[u]; cvec[BNW + nn] = cv1[u]; }
+  }
+  if constexpr (LN && EPI == EPI_VT) {
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { stat[mrow[i] - m0] = mean[i]; stat[BM + mrow[i] - m0] = rstd[i]; }
+    }
+  }
+
+  // per-lane fragment read addresses: sub-tile j reads weight row R_j of the tile image
+  int rb_sw[NJ], vq_sw[NJ], lb_sw[NJ];                        // swapped order: 8 consecutive output columns per lane
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int R;
+    if constexpr (EPI == EPI_GEGLU) {   // j = 0, 1: value columns o = 8 (c >> 2) + 4 j + (c & 3); j = 2, 3: their gates
+      const int o = 8 * (c >> 2) + 4 * (j & 1) + (c & 3);
+      R = (o >> 4) * 32 + (o & 15) + 16 * (j >> 1);
+    } else {
+      R = 32 * (j >> 1) + 8 * (c >> 2) + 4 * (j & 1) + (c & 3);
+    }
+    rb_sw[j] = R * (K * 2);
+    vq_sw[j] = (q ^ pg_hsw(R)) * 16;
+    lb_sw[j] = R * (p.Rp * 2) + q * 8;
+  }
+  const int rb_vt = c * (K * 2), vq_vt = (q ^ pg_hsw(c)) * 16;   // natural order (V^T tiles): sub-tile j reads row 16 j + c
+
+  float rs1[MI], rs2[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) rs1[i] = rs2[i] = 0.f;
+  f32x4 vmean[MI], vrstd[MI];                                 // V^T orientation: statistics of the 4 MI rows this lane owns
+  bool vstat_ready = false;
+
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) wait_vmcnt<P>(); else wait_vmcnt<0>();     // tile t landed (this wave's pieces); at most the next tile in flight
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): LDS writes / reads of the previous tile
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < T) issue(t + 2);
+    const char* const Ws = smem + (t % 3) * STG;
+    const int n_t = n_wg0 + t * NT;
+    const bool vt_tile = EPI == EPI_VT && n_t >= p.vt_col0;
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (!vt_tile) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          wf[j] = *reinterpret_cast<const bf16x8*>(Ws + rb_sw[j] + (((ks & 3) * 64) ^ vq_sw[j]) + (ks >> 2) * 256);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i][ks], acc[i][j], 0, 0, 0);
+      }
+      if constexpr (RT > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const char* brow = LB + t * NT * (p.Rp * 2) + lb_sw[j];
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(brow);
+          const bf16x4 hi = RT > 1 ? *reinterpret_cast<const bf16x4*>(brow + 32) : bf16x4{0, 0, 0, 0};
+          const bf16x8 bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, tf[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      // ---- epilogue, straight from the accumulators: lane (c, q) holds columns 8 q .. 8 q + 7 of each 32-column group ----
+      if constexpr (EPI == EPI_GEGLU) {
+        const int pv = (q >> 1) * 32 + (q & 1) * 8;           // packed index of the first value column; its gate: + 16
+        const float* cb = cvec + t * NT + pv;
+        const f32x4 cv_a = *reinterpret_cast<const f32x4*>(cb), cv_b = *reinterpret_cast<const f32x4*>(cb + 4);
+        const f32x4 cg_a = *reinterpret_cast<const f32x4*>(cb + 16), cg_b = *reinterpret_cast<const f32x4*>(cb + 20);
+        f32x4 sv_a, sv_b, sg_a, sg_b;
+        if constexpr (LN) {
+          const float* sb2 = cb + BNW;
+          sv_a = *reinterpret_cast<const f32x4*>(sb2); sv_b = *reinterpret_cast<const f32x4*>(sb2 + 4);
+          sg_a = *reinterpret_cast<const f32x4*>(sb2 + 16); sg_b = *reinterpret_cast<const f32x4*>(sb2 + 20);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float val = acc[i][e >> 2][e & 3], gate = acc[i][2 + (e >> 2)][e & 3];
+            const float cvv = e < 4 ? cv_a[e & 3] : cv_b[e & 3], cgg = e < 4 ? cg_a[e & 3] : cg_b[e & 3];
+            if constexpr (LN) {
+              const float svv = e < 4 ? sv_a[e & 3] : sv_b[e & 3], sgg = e < 4 ? sg_a[e & 3] : sg_b[e & 3];
+              val = rstd[i] * (val - mean[i] * svv) + cvv;
+              gate = rstd[i] * (gate - mean[i] * sgg) + cgg;
+            } else {
+              val += cvv;
+              gate += cgg;
+            }
+            o[e] = (bf16)(val * gelu_erf_f(gate));
+          }
+          if (mrow[i] < p.M) *reinterpret_cast<bf16x8*>(p.out + (long long)mrow[i] * p.out_ld + (n_t >> 1) + 8 * q) = o;
+        }
+      } else {
+#pragma unroll
+        for (int tp = 0; tp < NJ / 2; ++tp) {
+          const int nl = t * NT + 32 * tp + 8 * q;             // range-relative first column
+          const f32x4 c_a = *reinterpret_cast<const f32x4*>(cvec + nl), c_b = *reinterpret_cast<const f32x4*>(cvec + nl + 4);
+          f32x4 s_a, s_b;
+          if constexpr (LN) { s_a = *reinterpret_cast<const f32x4*>(cvec + BNW + nl); s_b = *reinterpret_cast<const f32x4*>(cvec + BNW + nl + 4); }
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            bf16x8 r8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (RES) {
+              const int rl = 4 * MI * (c >> 2) + 4 * i + (c & 3);
+              const int f = MI == 2 ? (((rl >> 1) & 1) | (((rl >> 3) & 3) << 1)) : ((rl >> 1) & 7);
+              r8 = *reinterpret_cast<const bf16x8*>(Ws + WT + (mw0 + rl) * (NT * 2) + (((4 * tp + q) ^ (f & (RCH - 1))) * 16));
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = acc[i][2 * tp + (e >> 2)][e & 3];
+              const float cc = e < 4 ? c_a[e & 3] : c_b[e & 3];
+              if constexpr (LN) v = rstd[i] * (v - mean[i] * (e < 4 ? s_a[e & 3] : s_b[e & 3])) + cc;
+              else v += cc;
+              if constexpr (RES) v += (float)r8[e];
+              o[e] = (bf16)v;
+              if constexpr (RSTAT) { const float f2 = (float)o[e]; rs1[i] += f2; rs2[i] = fmaf(f2, f2, rs2[i]); }
+            }
+            if (mrow[i] < p.M) *reinterpret_cast<bf16x8*>(p.out + (long long)mrow[i] * p.out_ld + n_wg0 + nl) = o;
+          }
+        }
+      }
+    } else if constexpr (EPI == EPI_VT) {
+      // ---- V^T tile: un-swapped operand order, lane (c, q) owns rows 4 MI q .. 4 MI q + 4 MI - 1 of column 16 j + c ----
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          wf[j] = *reinterpret_cast<const bf16x8*>(Ws + j * (16 * K * 2) + rb_vt + (((ks & 3) * 64) ^ vq_vt) + (ks >> 2) * 256);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i][ks], wf[j], acc[i][j], 0, 0, 0);
+      }
+      if constexpr (RT > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const char* brow = LB + (t * NT + 16 * j + c) * (p.Rp * 2) + q * 8;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(brow);
+          const bf16x4 hi = RT > 1 ? *reinterpret_cast<const bf16x4*>(brow + 32) : bf16x4{0, 0, 0, 0};
+          const bf16x8 bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], bfr, acc[i][j], 0, 0, 0);
+        }
+      }
+      if (LN && !vstat_ready) {                               // (uniform) first V^T tile: the statistics of the rows this lane owns
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          vmean[i] = *reinterpret_cast<const f32x4*>(stat + mw0 + 4 * MI * q + 4 * i);
+          vrstd[i] = *reinterpret_cast<const f32x4*>(stat + BM + mw0 + 4 * MI * q + 4 * i);
+        }
+        vstat_ready = true;
+      }
+      const int mq = m0 + mw0 + 4 * MI * q;                   // first of this lane's 4 MI rows
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int nl = t * NT + 16 * j + c;
+        const float cc = cvec[nl], ss = LN ? cvec[BNW + nl] : 0.f;
+        bf16 o[4 * MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][e];
+            if constexpr (LN) v = vrstd[i][e] * (v - vmean[i][e] * ss) + cc;
+            else v += cc;
+            o[4 * i + e] = (bf16)v;
+          }
+        bf16* const vrow = p.vt + (long long)(n_t + 16 * j + c - p.vt_col0) * p.vt_ld;
+        if (p.vt_vec >= 4 * MI) {                             // the lane's rows are one aligned group inside one sample
+          if (mq < p.M) {
+            const int b = fdiv(mq, p.fd_ohw), pix = mq - b * p.OHW;
+            bf16* dst = vrow + (long long)b * p.vt_bs + pix;
+            if constexpr (MI == 2) *reinterpret_cast<bf16x8*>(dst) = bf16x8{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+            else *reinterpret_cast<bf16x4*>(dst) = bf16x4{o[0], o[1], o[2], o[3]};
+          }
+        } else if (p.vt_vec == 4) {                           // MI == 2: two groups of four
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int mm = mq + 4 * i;
+            if (mm < p.M) {
+              const int b = fdiv(mm, p.fd_ohw), pix = mm - b * p.OHW;
+              *reinterpret_cast<bf16x4*>(vrow + (long long)b * p.vt_bs + pix) = bf16x4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+            }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4 * MI; ++u) {
+            const int mm = mq + u;
+            if (mm < p.M) {
+              const int b = fdiv(mm, p.fd_ohw), pix = mm - b * p.OHW;
+              vrow[(long long)b * p.vt_bs + pix] = o[u];
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (RSTAT) {
+    // LayerNorm hand-over: this range's (sum, sum of squares) of every row, of the values AS STORED (bf16)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float a = rs1[i], b = rs2[i];
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (q == 0 && mrow[i] < p.M) *reinterpret_cast<float2*>(p.rowstat + ((long long)mrow[i] * p.nranges + nr) * 2) = make_float2(a, b);
+    }
+  }
+#endif
+}
+
+template <int K, int NT, int MI, int RT, int EPI, int FL>
+int pg_launch(const PgArgs& a, hipStream_t st) {
+  constexpr int BM = 64 * MI;
+  constexpr int STG = NT * K * 2 + ((FL & PG_RES) ? BM * NT * 2 : 0);
+  const int BNW = a.tpr * NT;
+  const int lds = (a.tpr < 3 ? a.tpr : 3) * STG + 2 * BM * 4 + 2 * BNW * 4 + BNW * a.Rp * 2;
+  if (lds > 160 * 1024) {
+    aldm_set_error("pgemm: %d B of LDS (K %d, tile %d x %d, %d tiles per range)", lds, K, BM, NT, a.tpr);
+    return ALDM_E_UNSUPPORTED;
+  }
+  auto kern = pgemm_kernel<K, NT, MI, RT, EPI, FL>;
+  static unsigned long long attr_done = 0;
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024, &attr_done, "pgemm")) return rc;
+  const int grid = cdiv(a.M, BM) * a.nranges;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+  return aldm_launch_status("pgemm");
+}
+
+// the instantiations the transformer blocks use; anything else is refused (the caller keeps aldm_igemm)
+template <int K, int NT, int MI>
+int pg_dispatch(const PgArgs& a, int rt, int epi, int fl, hipStream_t st) {
+#define PG_CASE(RT_, EPI_, FL_) if (rt == (RT_) && epi == (EPI_) && fl == (FL_)) return pg_launch<K, NT, MI, RT_, EPI_, FL_>(a, st);
+  PG_CASE(0, EPI_STD, 0)                                     // plain linear (+ bias)
+  PG_CASE(0, EPI_STD, PG_RSTAT)                              // proj_in: + statistics for norm1
+  PG_CASE(0, EPI_STD, PG_RES)
+  PG_CASE(0, EPI_STD, PG_RES | PG_RSTAT)                     // to_out.0 without an adapter
+  PG_CASE(1, EPI_STD, 0)                                     // a LoRA-wrapped linear on its own
+  PG_CASE(2, EPI_STD, 0)
+  PG_CASE(1, EPI_STD, PG_RES)
+  PG_CASE(1, EPI_STD, PG_RES | PG_RSTAT)                     // to_out.0 + LoRA + residual + statistics for the next norm
+  PG_CASE(2, EPI_STD, PG_RES)
+  PG_CASE(2, EPI_STD, PG_RES | PG_RSTAT)                     //   (adapter rank 17 .. 32)
+  PG_CASE(0, EPI_VT, PG_LN)                                  // to_q | to_k | to_v, LayerNorm folded
+  PG_CASE(1, EPI_VT, PG_LN)                                  //   + LoRA (combined rank <= 16)
+  PG_CASE(2, EPI_VT, PG_LN)                                  //   + LoRA (combined rank <= 32)
+  PG_CASE(0, EPI_VT, 0)
+  PG_CASE(1, EPI_VT, 0)
+  PG_CASE(2, EPI_VT, 0)
+  if constexpr (NT == 64) {
+    PG_CASE(0, EPI_GEGLU, PG_LN)                             // GEGLU projection, LayerNorm folded
+    PG_CASE(0, EPI_GEGLU, 0)
+  }
+#undef PG_CASE
+  aldm_set_error("pgemm: no instantiation for LoRA tiles %d, epilogue %d, flags %d (tile 64*%d x %d)", rt, epi, fl, MI, NT);
+  return ALDM_E_UNSUPPORTED;
+}
+
+template <int K>
+int pg_dispatch_k(const PgArgs& a, int mi, int nt, int rt, int epi, int fl, hipStream_t st) {
+  if (nt == 64 && mi == 1) return pg_dispatch<K, 64, 1>(a, rt, epi, fl, st);
+  if (nt == 32 && mi == 1) return pg_dispatch<K, 32, 1>(a, rt, epi, fl, st);
+  if constexpr (K <= 384) {                                   // MI = 2 keeps 64 (96) registers of x per lane; K = 640 would need 160
+    if (nt == 64 && mi == 2) return pg_dispatch<K, 64, 2>(a, rt, epi, fl, st);
+    if (nt == 32 && mi == 2) return pg_dispatch<K, 32, 2>(a, rt, epi, fl, st);
+  }
+  aldm_set_error("pgemm: no tile 64*%d x %d for K = %d", mi, nt, K);
+  return ALDM_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int aldm_pgemm_supported(int K) { return K == 256 || K == 384 || K == 640; }
+
+// Launch shape.  These GEMMs are bound by what one CU can pull through its vector-memory path (~64 B/clk), not by the MFMA rate:
+// a workgroup reads 64 mi rows of x (K 2 B each) once and tiles_per_range * nt (+ LoRA-A) weight rows.  Pick the shape with the
+// fewest bytes per CU over ceil(workgroups / 256) rounds; a fixed cost per workgroup stands for its prologue / epilogue latency.
+extern "C" int aldm_pgemm_plan(aldm_pgemm_t* g) {
+  ALDM_CHECK_ARG(g && aldm_pgemm_supported(g->K) && g->M > 0 && g->N > 0 && g->N % 64 == 0, "pgemm_plan: bad shape");
+  if (g->mi && g->nt && g->tiles_per_range) return ALDM_OK;
+  const int rt = g->Rp ? (g->ranks_used <= 16 ? 1 : 2) : 0;
+  double best = 1e30;
+  int bmi = 0, bnt = 0, btpr = 0;
+  for (int mi = 1; mi <= (g->K <= 384 ? 2 : 1); ++mi) {
+    if (g->mi && g->mi != mi) continue;
+    for (int nt = 32; nt <= 64; nt += 32) {
+      if ((g->nt && g->nt != nt) || (g->geglu && nt != 64) || (g->vt && g->vt_col0 % nt)) continue;
+      const int ntiles = g->N / nt;
+      for (int tpr = 1; tpr <= ntiles && tpr * nt <= 512; ++tpr) {
+        if (ntiles % tpr || (g->tiles_per_range && g->tiles_per_range != tpr)) continue;
+        if (g->max_ranges > 0 && ntiles / tpr > g->max_ranges) continue;
+        const int bm = 64 * mi;
+        const long long stg = (long long)nt * g->K * 2 + (g->res ? bm * nt * 2 : 0);
+        const long long lds = (tpr < 3 ? tpr : 3) * stg + 2 * bm * 4 + 2 * tpr * nt * 4 + (long long)tpr * nt * g->Rp * 2;
+        if (lds > 160 * 1024) continue;
+        const long long wgs = (long long)cdiv(g->M, bm) * (ntiles / tpr);
+        const double bytes = (double)bm * g->K * 2 + (double)(tpr * nt + 16 * rt) * g->K * 2 + (g->res ? (double)bm * tpr * nt * 2 : 0.0) +
+                             (double)bm * tpr * nt * (g->geglu ? 1 : 2);
+        const double rounds = (double)((wgs + 255) / 256);
+        const double cost = rounds * (bytes + 48.0 * 1024);
+        if (cost < best) { best = cost; bmi = mi; bnt = nt; btpr = tpr; }
+      }
+    }
+  }
+  if (!bmi) {
+    aldm_set_error("pgemm_plan: no launch shape for M %d N %d K %d (mi %d nt %d tiles_per_range %d)", g->M, g->N, g->K, g->mi, g->nt, g->tiles_per_range);
+    return ALDM_E_UNSUPPORTED;
+  }
+  g->mi = bmi; g->nt = bnt; g->tiles_per_range = btpr;
+  return ALDM_OK;
+}
+
+extern "C" int aldm_pgemm(const aldm_pgemm_t* g0, void* stream) {
+  ALDM_CHECK_ARG(g0 && g0->x && g0->w && g0->out, "pgemm: null x / w / out");
+  aldm_pgemm_t gg = *g0;
+  if (!(gg.mi && gg.nt && gg.tiles_per_range)) {
+    if (int rc = aldm_pgemm_plan(&gg)) return rc;
+  }
+  const aldm_pgemm_t* g = &gg;
+  ALDM_CHECK_ARG(aldm_pgemm_supported(g->K), "pgemm: K must be 256, 384 or 640 (got %d)", g->K);
+  ALDM_CHECK_ARG(g->M > 0 && g->N > 0 && g->N % 64 == 0, "pgemm: N must be a multiple of 64 (got %d)", g->N);
+  ALDM_CHECK_ARG((unsigned long long)g->M * g->K * 2 < 0x80000000ull && (unsigned long long)g->N * g->K * 2 < 0x80000000ull,
+                 "pgemm: operands beyond 32-bit buffer offsets");
+  const int mi = g->mi, nt = g->nt;
+  ALDM_CHECK_ARG((mi == 1 || mi == 2) && (nt == 32 || nt == 64), "pgemm: mi must be 1 / 2 and nt 32 / 64 (got %d, %d)", mi, nt);
+  ALDM_CHECK_ARG(g->tiles_per_range > 0 && (g->N / nt) % g->tiles_per_range == 0 && g->tiles_per_range * nt <= 512,
+                 "pgemm: tiles_per_range %d must divide N / nt = %d and span at most 512 columns", g->tiles_per_range, g->N / nt);
+  int rt = 0;
+  if (g->Rp) {
+    ALDM_CHECK_ARG(g->lora_a && g->lora_b && (g->Rp == 32 || g->Rp == 64) && g->ranks_used > 0 && g->ranks_used <= 32 && g->ranks_used <= g->Rp,
+                   "pgemm: LoRA needs lora_a / lora_b, Rp 32 / 64 and 1 <= ranks_used <= 32 (got Rp %d, %d ranks)", g->Rp, g->ranks_used);
+    rt = g->ranks_used <= 16 ? 1 : 2;
+    ALDM_CHECK_ARG(!g->ln_s || (g->ln_sa && g->ln_ca), "pgemm: folded LayerNorm with LoRA needs ln_sa / ln_ca");
+  }
+  ALDM_CHECK_ARG(!g->ln_s || (g->ln_parts && g->ln_nparts > 0), "pgemm: the folded LayerNorm takes its statistics from ln_parts");
+  ALDM_CHECK_ARG(!(g->geglu && (g->vt || g->res || g->rowstat_out || g->Rp)), "pgemm: GEGLU launches take no V^T / residual / statistics / LoRA");
+  ALDM_CHECK_ARG(!g->geglu || nt == 64, "pgemm: GEGLU needs nt = 64");
+  ALDM_CHECK_ARG(!(g->vt && (g->res || g->rowstat_out)), "pgemm: V^T launches take no residual / statistics");
+  ALDM_CHECK_ARG(!g->vt || (g->vt_col0 > 0 && g->vt_col0 % nt == 0 && g->OHW > 0 && g->M % g->OHW == 0 && g->vt_ld >= g->OHW),
+                 "pgemm: vt_col0 %d must be a positive multiple of nt %d, M a multiple of OHW", g->vt_col0, nt);
+  ALDM_CHECK_ARG(g->out_ld % 8 == 0 && ((uintptr_t)g->out & 15) == 0, "pgemm: out rows must be 16-byte aligned");
+  ALDM_CHECK_ARG(!g->res || ((unsigned long long)g->M * g->out_ld * 2 < 0x80000000ull && ((uintptr_t)g->res & 15) == 0), "pgemm: residual too large / misaligned");
+
+  PgArgs a;
+  a.x = (const bf16*)g->x; a.w = (const bf16*)g->w; a.lora_a = (const bf16*)g->lora_a; a.lora_b = (const bf16*)g->lora_b;
+  a.bias = g->bias; a.ln_s = g->ln_s; a.ln_sa = g->ln_sa; a.ln_ca = g->ln_ca; a.ln_parts = g->ln_parts;
+  a.res = (const bf16*)g->res; a.out = (bf16*)g->out; a.vt = (bf16*)g->vt; a.rowstat = g->rowstat_out;
+  a.M = g->M; a.N = g->N; a.Rp = g->Rp; a.ln_np = g->ln_nparts; a.out_ld = g->out_ld;
+  a.vt_col0 = g->vt ? g->vt_col0 : 0x7fffffff; a.vt_ld = g->vt_ld; a.OHW = g->OHW > 0 ? g->OHW : g->M; a.vt_bs = g->vt_batch_stride;
+  a.vt_vec = 1;
+  if (g->vt) {
+    const bool al8 = a.OHW % 8 == 0 && g->vt_ld % 8 == 0 && g->vt_batch_stride % 8 == 0 && ((uintptr_t)g->vt & 15) == 0;
+    const bool al4 = a.OHW % 4 == 0 && g->vt_ld % 4 == 0 && g->vt_batch_stride % 4 == 0 && ((uintptr_t)g->vt & 7) == 0;
+    a.vt_vec = al8 ? 8 : (al4 ? 4 : 1);
+  }
+  a.fd_ohw = make_fastdiv((unsigned)a.OHW);
+  a.tpr = g->tiles_per_range; a.nranges = g->N / nt / g->tiles_per_range; a.fd_nr = make_fastdiv((unsigned)a.nranges);
+  a.ln_eps = g->ln_eps;
+  const int epi = g->geglu ? EPI_GEGLU : (g->vt ? EPI_VT : EPI_STD);
+  const int fl = (g->ln_s ? PG_LN : 0) | (g->res ? PG_RES : 0) | (g->rowstat_out ? PG_RSTAT : 0);
+  hipStream_t st = (hipStream_t)stream;
+  switch (g->K) {
+    case 256: return pg_dispatch_k<256>(a, mi, nt, rt, epi, fl, st);
+    case 384: return pg_dispatch_k<384>(a, mi, nt, rt, epi, fl, st);
+    default: return pg_dispatch_k<640>(a, mi, nt, rt, epi, fl, st);
+  }
+}

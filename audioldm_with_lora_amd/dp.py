@@ -67,6 +67,56 @@ class ProjectConfiguration:
             self.logging_dir = self.project_dir
 
 
+class ShardedLoader:
+    """What `accelerator.prepare(dataloader)` returns under N > 1 processes: accelerate's DataLoaderShard / BatchSamplerShard with
+    its defaults (split_batches=False, even_batches=True).  The loader's batch size stays the PER-PROCESS batch size; of every N
+    consecutive batches process r takes the r-th, so the ranks consume disjoint data and the global batch is N x batch_size
+    [REF script/train/train_audioldm_lora.py:421-430,445-447].  A last, incomplete group is completed by wrapping around to the
+    first batches of the epoch, so that every rank runs the same number of steps (no rank waits in an all-reduce forever)."""
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __len__(self):
+        return (len(self.loader) + self.world - 1) // self.world
+
+    def __getattr__(self, name):                             # batch_size, dataset, ... of the wrapped loader
+        return getattr(self.loader, name)
+
+    def __iter__(self):
+        first, group = [], []
+        for batch in self.loader:
+            if len(first) < self.world:
+                first.append(batch)
+            group.append(batch)
+            if len(group) == self.world:
+                yield group[self.rank]
+                group = []
+        if group:                                            # incomplete last group: pad from the start of the epoch
+            i = 0
+            while len(group) < self.world:
+                group.append(first[i % len(first)])
+                i += 1
+            yield group[self.rank]
+
+
+class PreparedScheduler:
+    """accelerate's AcceleratedScheduler (split_batches=False): one `lr_scheduler.step()` of the loop advances the wrapped schedule
+    once PER PROCESS, which is why the reference sizes it with `num_training_steps = max_train_steps * num_processes`
+    [REF script/train/train_audioldm_lora.py:438-443,564] -- after k optimiser steps the schedule stands at k N of T N, i.e. at the
+    same learning rate as a single process at k of T."""
+
+    def __init__(self, scheduler, num_processes):
+        self.scheduler, self.num_processes = scheduler, num_processes
+
+    def step(self, *a, **k):
+        for _ in range(self.num_processes):
+            self.scheduler.step(*a, **k)
+
+    def __getattr__(self, name):                             # get_last_lr, state_dict, last_epoch, ...
+        return getattr(self.scheduler, name)
+
+
 def _inner_unet(model):
     """PeftModel -> the wrapped UNet (the object that owns the training engine); anything else unchanged."""
     return getattr(getattr(model, "base_model", None), "model", model)
@@ -132,9 +182,13 @@ class Accelerator:
 
     # ---- model / optimiser plumbing ----
     def prepare(self, *objs):
-        """Registers what the loop will use.  A LoRA-wrapped UNet gets its training engine here: the LoRA parameters move into
-        one flat fp32 buffer and rank 0's copy is broadcast (DDP's constructor broadcast, C3, LoRA buffer only)."""
+        """Registers what the loop will use and returns the objects the loop must use from here on, in the same order
+        [REF train:445-447].  A LoRA-wrapped UNet gets its training engine here: the LoRA parameters move into one flat fp32
+        buffer and rank 0's copy is broadcast (DDP's constructor broadcast, C3, LoRA buffer only).  Under N > 1 processes a
+        DataLoader comes back rank-sharded (ShardedLoader) and the LR scheduler comes back stepping N times per call
+        (PreparedScheduler), exactly as accelerate prepares them; with one process both come back unchanged."""
         from . import optim
+        out = []
         for o in objs:
             inner = _inner_unet(o)
             if isinstance(o, torch.nn.Module) and hasattr(inner, "_has_trainable_lora") and inner._has_trainable_lora():
@@ -146,7 +200,12 @@ class Accelerator:
                 self._optimizers.append(o)
             elif isinstance(o, optim.PolynomialLR):
                 self._schedulers.append(o)
-        return objs if len(objs) != 1 else objs[0]
+                if self.num_processes > 1:
+                    o = PreparedScheduler(o, self.num_processes)
+            elif isinstance(o, torch.utils.data.DataLoader) and self.num_processes > 1:
+                o = ShardedLoader(o, self.process_index, self.num_processes)
+            out.append(o)
+        return tuple(out) if len(out) != 1 else out[0]
 
     def unwrap_model(self, model):
         """accelerate strips only the distributed wrapper (`.module`); a PeftModel stays a PeftModel [REF train:347-350,577,598]."""

@@ -464,6 +464,19 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     if out_batch_stride is None:
         assert out_pix_stride == 1 and out_pix_offset == 0, "strided output rows need an explicit batch stride"
         out_batch_stride = OH * OW * out_ld
+    if (PGEMM and tile == 0 and ring == 0 and KH == 1 and KW == 1 and stride == (1, 1) and pad == (0, 0) and up_size is None
+            and not in_dilate and in_act == ACT_NONE and x2 is None and x3 is None and pw.Kpad == C1 and C1 in PGEMM_K
+            and pw.N % 64 == 0 and out.dtype == torch.bfloat16 and out_pix_stride == 1 and out_pix_offset == 0
+            and out_batch_stride == OH * OW * out_ld and out_ld % 8 == 0 and rowbias is None and out_act == ACT_NONE
+            and post_act == ACT_NONE and res2 is None and out2 is None and alpha == 1.0 and lora_t_out is None
+            and splits in (None, 1) and gn is None and not vt_dual
+            and not (qstats and OH * OW >= QSTATS_MIN_HW)
+            and (not pw.Rp or getattr(pw, "ranks_used", 99) <= 32)
+            and (pw.ln_s is None or ln_parts is not None)
+            and not (pw.geglu and (res is not None or vt is not None or pw.Rp or rowstats))
+            and not (vt is not None and (res is not None or rowstats or vt_col0 % 32 or vt_col0 <= 0))
+            and (res is None or (res.is_contiguous() and res.numel() == B * OH * OW * out_ld))):
+        return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts)
     a = IgemmArgs()
     if x3 is not None:
         for t in (x3, x4):
@@ -594,6 +607,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
 
     if qs is not None:
         out.qstats = qs                                     # (a Python attribute of this tensor object: skip lists keep the object)
+    elif hasattr(out, "qstats"):
+        del out.qstats                                      # a caller-supplied buffer rewritten without statistics: drop the stale table
 
     def finish():
         # the GroupNorm of gn=: over the partial tiles when the launch deferred its reduce, else over the bf16 output
@@ -625,6 +640,55 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         return y if gn_defer else finish()
     check(_launch(label, flops, nbytes, lambda: lib.aldm_igemm(C.byref(a), _stream())), "aldm_igemm")
     return finish()
+
+
+# ---- the transformer blocks' projection GEMMs (csrc/pgemm.hip) ---------------------------------------------------------------
+PGEMM = os.environ.get("ALDM_NO_PGEMM") != "1"
+PGEMM_K = (256, 384, 640)
+PGEMM_CFG = {}                                               # (M, N, K, kind) -> (mi, nt, tiles_per_range): tools/tune_pgemm.py
+
+
+def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowstats, ln_parts):
+    """conv()'s 1x1 / short-K case on aldm_pgemm: same operands, same results (to rounding), a kernel built for it."""
+    lib = _lib.load()
+    a = _lib.PgemmArgs()
+    a.x, a.w, a.M, a.N, a.K = x.data_ptr(), pw.w.data_ptr(), M, pw.N, K
+    a.bias = pw.bias.data_ptr() if pw.bias is not None else None
+    if pw.ln_s is not None:
+        assert ln_parts.dtype == torch.float32 and ln_parts.is_contiguous() and ln_parts.dim() == 3 and ln_parts.shape[2] == 2
+        assert ln_parts.shape[0] == M, "ln_parts: one row of partials per GEMM row"
+        a.ln_s, a.ln_eps, a.ln_parts, a.ln_nparts = pw.ln_s.data_ptr(), pw.ln_eps, ln_parts.data_ptr(), ln_parts.shape[1]
+        if pw.Rp:
+            a.ln_sa, a.ln_ca = pw.ln_sa.data_ptr(), pw.ln_ca.data_ptr()
+    elif ln_parts is not None:
+        raise _lib.AldmError("conv: ln_parts without a LayerNorm-folded weight pack (pack_linear_ln)")
+    if pw.Rp:
+        a.lora_a, a.lora_b, a.Rp, a.ranks_used = pw.lora_a.data_ptr(), pw.lora_b.data_ptr(), pw.Rp, pw.ranks_used
+    a.geglu = 1 if pw.geglu else 0
+    a.res = res.data_ptr() if res is not None else None
+    a.out, a.out_ld = out.data_ptr(), out_ld
+    if vt is not None:
+        a.vt, a.vt_col0, a.vt_ld, a.vt_batch_stride, a.OHW = vt.data_ptr(), vt_col0, vt_ld, vt_bs, OHW
+    kind = ("g" if pw.geglu else "") + ("v" if vt is not None else "") + ("r" if res is not None else "") + (f"l{pw.Rp}" if pw.Rp else "")
+    cfg = PGEMM_CFG.get((M, pw.N, K, kind))
+    if cfg is not None:
+        a.mi, a.nt, a.tiles_per_range = cfg
+    if rowstats:
+        a.max_ranges = 16                                    # consumers take at most 16 partial pairs per row (aldm_attn_block64)
+    check(lib.aldm_pgemm_plan(C.byref(a)), "aldm_pgemm_plan")
+    stats = None
+    if rowstats:
+        stats = torch.empty(M, pw.N // (a.nt * a.tiles_per_range), 2, dtype=torch.float32, device=x.device)
+        a.rowstat_out = stats.data_ptr()
+    ncols = pw.N // 2 if pw.geglu else (vt_col0 if vt is not None else pw.N)
+    flops = 2.0 * M * pw.N * K + (2.0 * M * pw.Rp * (K + pw.N) if pw.Rp else 0.0)
+    nbytes = 2.0 * (M * K + pw.N * K + M * ncols)
+    label = (f"pgemm_{64 * a.mi}x{a.nt}x{a.tiles_per_range}_r{pw.Rp}{'_vt' if vt is not None else ''}"
+             f"|M{M} N{pw.N} K{K}{' geglu' if pw.geglu else ''}")
+    if hasattr(out, "qstats"):
+        del out.qstats                                       # (see conv(): never leave a stale GroupNorm table on a rewritten buffer)
+    check(_launch(label, flops, nbytes, lambda: lib.aldm_pgemm(C.byref(a), _stream())), "aldm_pgemm")
+    return (out, stats) if rowstats else out
 
 
 def linear(x2d: torch.Tensor, pw: PackedW, **kw):
@@ -665,7 +729,8 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     q1, q2 = getattr(x, "qstats", None), (getattr(x2, "qstats", None) if x2 is not None else None)
     Cg = (C1 + C2) // groups
     if (q1 is not None and (x2 is None or q2 is not None) and (C1 + C2) % groups == 0 and Cg % 4 == 0 and C1 % Cg == 0
-            and C1 % 8 == 0 and C2 % 8 == 0 and groups <= 64 and x.is_contiguous() and (x2 is None or x2.is_contiguous())):
+            and C1 % 8 == 0 and C2 % 8 == 0 and groups <= 64 and (C1 + C2) // 8 <= 256
+            and x.is_contiguous() and (x2 is None or x2.is_contiguous())):
         # one coalesced pass: the producing convolution(s) handed the statistics over
         check(_launch(f"groupnorm_apply|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm_apply(
             _p(x), _p(q1.table), q1.bm, q1.tpi, _p(x2), _p(q2.table) if q2 is not None else None, q2.bm if q2 is not None else 0,
@@ -701,6 +766,9 @@ def attention(qk, vt, B, N, H, d, out=None, kv_len=None, fp8=False, prescaled=Fa
     k_ptr = C.c_void_p(qk.data_ptr() + Cc * 2)
     lib = _lib.load()
     if kv_len is not None:
+        if prescaled or fp8:
+            raise _lib.AldmError("attention: the varlen kernel applies d^-0.5 itself and has no fp8 form -- a pre-scaled Q (or "
+                                 "fp8=True) with kv_len would be scaled twice / silently ignored")
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_cuda
         check(_launch(f"attention_varlen_d{d}_n{N}", 4.0 * B * N * N * Cc, 2.0 * 4 * B * N * Cc, lambda: lib.aldm_attention_varlen(
             q_ptr, qk.shape[1], k_ptr, qk.shape[1], _p(vt), vt.shape[2], vt.stride(0), B, N, H, d, 1.0 / math.sqrt(d),

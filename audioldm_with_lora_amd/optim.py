@@ -76,6 +76,9 @@ class AdamW:
         sd = {"step": self._step, "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
         if flat is not None and whole:
             sd["m"], sd["v"] = flat.m.detach().cpu(), flat.v.detach().cpu()
+        if self.state:                                       # parameters outside a flat buffer keep their moments here
+            index = {id(p): i for i, p in enumerate(self.params)}
+            sd["state"] = {index[k]: {"m": st["m"].detach().cpu(), "v": st["v"].detach().cpu()} for k, st in self.state.items()}
         return sd
 
 

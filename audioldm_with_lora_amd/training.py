@@ -344,10 +344,28 @@ class _UNetTrainFn(torch.autograd.Function):
 def trainer_of(unet, create=True):
     """The training engine attached to a UNet (created on first use: flattens the LoRA parameters, builds the fused sites)."""
     tr = getattr(unet, "_trainer", None)
+    old = None
     if tr is not None and not tr.flat.intact():
-        tr = None                                            # the parameters were moved / reloaded: rebuild
+        old, tr = tr, None                                   # the LoRA parameters were moved / re-created: rebuild
     if tr is None and create:
-        tr = LoraTrainer(unet, None, use_graph=False)
+        if old is not None:
+            tr = LoraTrainer(unet, old.scheduler, lr=old.lr0, betas=old.betas, weight_decay=old.wd, eps=old.eps,
+                             max_train_steps=old.max_train_steps, lr_end=old.lr_end, power=old.power, use_graph=old.use_graph)
+            if tr.flat.names != old.flat.names or tr.flat.n != old.flat.n:
+                raise ops._lib.AldmError("trainer_of: the set of LoRA parameters changed under a live training engine -- its AdamW "
+                                         "moments cannot be carried over; build a new LoraTrainer / optimizer explicitly")
+            # the moments (and the step count that bias-corrects them) belong to the parameters, not to the buffer they lived in
+            tr.flat.m.copy_(old.flat.m.to(tr.flat.m.device))
+            tr.flat.v.copy_(old.flat.v.to(tr.flat.v.device))
+            tr.step_count = old.step_count
+        else:
+            tr = LoraTrainer(unet, None, use_graph=False)
+    elif tr is not None and tr.weights_version != unet._weights_version:
+        # the FROZEN weights may have changed in place (load_state_dict of the base, a no-op .to()): the LoRA views are intact,
+        # but the engine's packed copies of the base weights (plan + LoraSite operands) are stale
+        tr._build_sites()
+        tr.graph, tr._static, tr._eager_steps = None, None, 0
+        tr.weights_version = unet._weights_version
     return tr
 
 
@@ -371,6 +389,7 @@ class LoraTrainer:
         self.ac_dev = scheduler.alphas_cumprod.to(self.dev, torch.float32) if scheduler is not None else None
         self._tape = None
         self._build_sites()
+        self.weights_version = unet._weights_version
         unet.__dict__["_trainer"] = self                     # plain attribute (not a submodule): unet(...) in training mode finds it
         self.tnb = ops.TnBatch(4 * len(self.sites) + 8, self.dev)       # <= 2 sites per attention, 2 products per site
         dp.broadcast_(self.flat.params, src=0)                  # DDP's initial parameter broadcast (C3), LoRA buffer only

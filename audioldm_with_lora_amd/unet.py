@@ -359,6 +359,7 @@ class UNet2DConditionModel(nn.Module):
         self.num_upsamplers = len(boc) - 1
         self._plan = None
         self._plan_version = 0        # bumped whenever the packed operands may be stale (see invalidate_packed)
+        self._weights_version = 0     # bumped when the FROZEN weights may have changed (state load, .to()): training.trainer_of
 
     # ---- drop-in plumbing ----
     @classmethod
@@ -398,12 +399,15 @@ class UNet2DConditionModel(nn.Module):
 
     def _apply(self, fn, *a, **k):
         # (a training engine attached to this UNet survives a no-op .to(): training.trainer_of() checks that the LoRA
-        # parameters still alias its flat buffer and rebuilds only when they were really moved)
+        # parameters still alias its flat buffer and rebuilds only when they were really moved; it re-packs its copies of
+        # the frozen weights whenever _weights_version moved)
         self.invalidate_packed()
+        self._weights_version += 1
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self.invalidate_packed()
+        self._weights_version += 1
         return super().load_state_dict(*a, **k)
 
     # ---- packing ----

@@ -131,6 +131,42 @@ size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p);
 int aldm_igemm_effective_splits(const aldm_igemm_t* p);
 
 /* ------------------------------------------------------------------------------------------
+ * Projection GEMM of the transformer blocks: out[M][N] = epilogue(x[M][K] w[N][K]^T), K = 256 / 384 / 640.
+ * The linear layers of BasicTransformerBlock / Transformer2DModel under UNet2DConditionModel.forward
+ * [REF script/train/train_audioldm_lora.py:539-546] (diffusers Attention.to_q / to_k / to_v / to_out.0, GEGLU.proj,
+ * Transformer2DModel.proj_in) with peft lora.Linear fused [REF script/train/train_audioldm_lora.py:378-385].  Same operand
+ * packing and the same arithmetic as aldm_igemm on a 1x1 filter; a kernel built for short K (csrc/pgemm.hip): x fragments
+ * stay in registers for the whole K, weight tiles stream through an LDS-DMA ring, accumulators are stored straight from
+ * registers.  Epilogues: bias; folded LayerNorm (ln_s + ln_parts, as aldm_igemm_t); LoRA (combined rank <= 32); residual
+ * `res` (addressed like out); columns >= vt_col0 stored token-major (vt); GEGLU (w rows in (16 value | 16 gate) blocks);
+ * rowstat_out [M][N / (nt * tiles_per_range)][2] = per-row (sum, sum of squares) of the stored values per column range.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x;            /* [M][K] bf16 */
+  const void* w;            /* [N][K] bf16 */
+  int M, N, K;
+  const float* bias;        /* [N] fp32 or null (with ln_s: c_n = W beta + bias) */
+  const float* ln_s; const float* ln_sa; const float* ln_ca; float ln_eps;
+  const float* ln_parts; int ln_nparts;     /* [M][ln_nparts][2]: required with ln_s */
+  const void* lora_a;       /* [Rp][K] bf16 */
+  const void* lora_b;       /* [N][Rp] bf16, pre-scaled */
+  int Rp, ranks_used;       /* Rp 0 / 32 / 64; rows of lora_a that are not padding (<= 32) */
+  int geglu;                /* out has N / 2 columns */
+  const void* res;          /* bf16 [M][out_ld] or null */
+  void* out; int out_ld;    /* bf16; out_ld % 8 == 0 */
+  void* vt; int vt_col0; int vt_ld; long long vt_batch_stride; int OHW;   /* vt[b][n - vt_col0][pix], row m = b * OHW + pix */
+  float* rowstat_out;
+  /* launch shape: a workgroup owns 64 * mi rows and tiles_per_range N-tiles of nt columns.  0 = let aldm_pgemm_plan choose. */
+  int mi, nt, tiles_per_range;
+  int max_ranges;           /* plan only: at most this many column ranges per row (= partials per row of rowstat_out); 0 = any */
+} aldm_pgemm_t;
+
+int aldm_pgemm_supported(int K);
+/* fills mi / nt / tiles_per_range where they are 0 (the caller sizes rowstat_out from them); returns 0 or ALDM_E_* */
+int aldm_pgemm_plan(aldm_pgemm_t* p);
+int aldm_pgemm(const aldm_pgemm_t* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over channels-last x [B][HW][C1] (optionally the virtual channel
  * concat [x | x2], C = C1 + C2) -> y [B][HW][C] bf16.  One workgroup per (batch, group); stats in fp32.
  * F.group_norm under ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out, VAE group_norm

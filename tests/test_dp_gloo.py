@@ -72,6 +72,62 @@ def test_flat_allreduce_equals_single_process_gradient(tmp_path):
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6)
 
 
+def _prepare_worker(rank, world, port, out):
+    """accelerator.prepare(dataloader, lr_scheduler) under two processes: what each rank then sees in the loop"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from audioldm_with_lora_amd import dp, optim
+    assert dp.init_from_env(backend="gloo") == world
+    acc = dp.Accelerator()
+    data = torch.utils.data.TensorDataset(torch.arange(14.0))
+    loader = torch.utils.data.DataLoader(data, batch_size=2, shuffle=False)           # 7 batches: an incomplete last group
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = optim.AdamW([p], lr=1e-3)
+    max_train_steps = 10
+    sch = optim.get_scheduler("polynomial", optimizer=opt, num_warmup_steps=0, num_training_steps=max_train_steps * acc.num_processes)
+    opt2, loader2, sch2 = acc.prepare(opt, loader, sch)
+    assert opt2 is opt and len(loader2) == 4 and loader2.batch_size == 2
+    seen, lrs = [], []
+    for (batch,) in loader2:
+        seen.append(batch.tolist())
+        sch2.step()                                             # [REF train:564]: once per optimiser step
+        lrs.append(sch2.get_last_lr()[0])
+    acc.wait_for_everyone()
+    torch.save({"seen": seen, "lrs": lrs, "epoch": sch2.last_epoch}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_prepare_shards_the_dataloader_and_steps_the_schedule_once_per_process(tmp_path):
+    """under N processes accelerate hands every rank different batches and advances the prepared LR schedule N times
+    per optimiser step (hence `num_training_steps = max_train_steps * num_processes` [REF train:442])."""
+    from audioldm_with_lora_amd import optim
+    out = str(tmp_path / "prep.pt")
+    mp.spawn(_prepare_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    # rank r takes the r-th of every two consecutive batches; the incomplete last group wraps around to the first batch
+    assert r0["seen"] == [[0.0, 1.0], [4.0, 5.0], [8.0, 9.0], [12.0, 13.0]]
+    assert r1["seen"] == [[2.0, 3.0], [6.0, 7.0], [10.0, 11.0], [0.0, 1.0]]
+    # the learning rate after k optimiser steps equals a single process's at k of max_train_steps
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = optim.AdamW([p], lr=1e-3)
+    single = optim.get_scheduler("polynomial", optimizer=opt, num_warmup_steps=0, num_training_steps=10)
+    want = []
+    for _ in range(4):
+        single.step()
+        want.append(single.get_last_lr()[0])
+    assert r0["epoch"] == r1["epoch"] == 8
+    assert all(abs(a - b) < 1e-15 for a, b in zip(r0["lrs"], want)) and r0["lrs"] == r1["lrs"]
+
+
+def test_single_process_prepare_returns_loader_and_schedule_unchanged():
+    from audioldm_with_lora_amd import dp, optim
+    acc = dp.Accelerator()
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.arange(4.0)), batch_size=2)
+    opt = optim.AdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-3)
+    sch = optim.get_scheduler("polynomial", optimizer=opt, num_warmup_steps=0, num_training_steps=5)
+    a, b = acc.prepare(loader, sch)
+    assert a is loader and b is sch
+
+
 def test_single_process_helpers_are_noops():
     from audioldm_with_lora_amd import dp
     b = torch.arange(4.0)
