@@ -69,6 +69,7 @@ class PgemmArgs(C.Structure):
         ("rowstat_out", C.c_void_p),
         ("mi", C.c_int), ("nt", C.c_int), ("tiles_per_range", C.c_int),
         ("max_ranges", C.c_int),
+        ("waves", C.c_int),
     ]
 
 

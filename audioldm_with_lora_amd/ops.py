@@ -472,10 +472,11 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             and splits in (None, 1) and gn is None and not vt_dual
             and not (qstats and OH * OW >= QSTATS_MIN_HW)
             and (not pw.Rp or getattr(pw, "ranks_used", 99) <= 32)
-            and (pw.ln_s is None or ln_parts is not None)
+            and (pw.ln_s is None or (ln_parts is not None and ln_parts.shape[1] <= 16))
             and not (pw.geglu and (res is not None or vt is not None or pw.Rp or rowstats))
             and not (vt is not None and (res is not None or rowstats or vt_col0 % 32 or vt_col0 <= 0))
-            and (res is None or (res.is_contiguous() and res.numel() == B * OH * OW * out_ld))):
+            and (res is None or (res.is_contiguous() and res.numel() == B * OH * OW * out_ld))
+            and PGEMM_CFG.get(_pgemm_key(B * OH * OW, pw, C1, res, vt)) != PGEMM_USE_IGEMM):
         return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts)
     a = IgemmArgs()
     if x3 is not None:
@@ -646,6 +647,20 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
 PGEMM = os.environ.get("ALDM_NO_PGEMM") != "1"
 PGEMM_K = (256, 384, 640)
 PGEMM_CFG = {}                                               # (M, N, K, kind) -> (mi, nt, tiles_per_range): tools/tune_pgemm.py
+PGEMM_TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pgemm_gfx950.json")
+if os.path.exists(PGEMM_TUNED_PATH) and os.environ.get("ALDM_NO_TUNED") != "1":
+    with open(PGEMM_TUNED_PATH) as _f:
+        for _k, _v in json.load(_f)["pgemm"].items():
+            _m, _n, _kk, _kind = _k.split("|")
+            PGEMM_CFG[(int(_m), int(_n), int(_kk), _kind)] = tuple(_v)
+
+
+PGEMM_USE_IGEMM = (0, 0, 0, 0)                               # table entry: this GEMM measured faster on aldm_igemm, keep it there
+
+
+def _pgemm_key(M, pw, K, res, vt):
+    kind = ("g" if pw.geglu else "") + ("v" if vt is not None else "") + ("r" if res is not None else "") + (f"l{pw.Rp}" if pw.Rp else "")
+    return (M, pw.N, K, kind)
 
 
 def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowstats, ln_parts):
@@ -669,10 +684,10 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
     a.out, a.out_ld = out.data_ptr(), out_ld
     if vt is not None:
         a.vt, a.vt_col0, a.vt_ld, a.vt_batch_stride, a.OHW = vt.data_ptr(), vt_col0, vt_ld, vt_bs, OHW
-    kind = ("g" if pw.geglu else "") + ("v" if vt is not None else "") + ("r" if res is not None else "") + (f"l{pw.Rp}" if pw.Rp else "")
-    cfg = PGEMM_CFG.get((M, pw.N, K, kind))
+    cfg = PGEMM_CFG.get(_pgemm_key(M, pw, K, res, vt))
     if cfg is not None:
-        a.mi, a.nt, a.tiles_per_range = cfg
+        a.mi, a.nt, a.tiles_per_range = cfg[:3]
+        a.waves = cfg[3] if len(cfg) > 3 else 4
     if rowstats:
         a.max_ranges = 16                                    # consumers take at most 16 partial pairs per row (aldm_attn_block64)
     check(lib.aldm_pgemm_plan(C.byref(a)), "aldm_pgemm_plan")
@@ -683,7 +698,7 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
     ncols = pw.N // 2 if pw.geglu else (vt_col0 if vt is not None else pw.N)
     flops = 2.0 * M * pw.N * K + (2.0 * M * pw.Rp * (K + pw.N) if pw.Rp else 0.0)
     nbytes = 2.0 * (M * K + pw.N * K + M * ncols)
-    label = (f"pgemm_{64 * a.mi}x{a.nt}x{a.tiles_per_range}_r{pw.Rp}{'_vt' if vt is not None else ''}"
+    label = (f"pgemm_{16 * a.mi * a.waves}x{a.nt}x{a.tiles_per_range}w{a.waves}_r{pw.Rp}{'_vt' if vt is not None else ''}"
              f"|M{M} N{pw.N} K{K}{' geglu' if pw.geglu else ''}")
     if hasattr(out, "qstats"):
         del out.qstats                                       # (see conv(): never leave a stale GroupNorm table on a rewritten buffer)

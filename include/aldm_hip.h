@@ -156,9 +156,11 @@ typedef struct {
   void* out; int out_ld;    /* bf16; out_ld % 8 == 0 */
   void* vt; int vt_col0; int vt_ld; long long vt_batch_stride; int OHW;   /* vt[b][n - vt_col0][pix], row m = b * OHW + pix */
   float* rowstat_out;
-  /* launch shape: a workgroup owns 64 * mi rows and tiles_per_range N-tiles of nt columns.  0 = let aldm_pgemm_plan choose. */
+  /* launch shape: a workgroup of `waves` (4 / 8) wave64s owns 16 * mi * waves rows and tiles_per_range N-tiles of nt columns.
+     0 = let aldm_pgemm_plan choose. */
   int mi, nt, tiles_per_range;
   int max_ranges;           /* plan only: at most this many column ranges per row (= partials per row of rowstat_out); 0 = any */
+  int waves;
 } aldm_pgemm_t;
 
 int aldm_pgemm_supported(int K);

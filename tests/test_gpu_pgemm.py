@@ -50,21 +50,23 @@ def labels(ops):
 
 
 def shapes_for(K, N, geglu=False, vt_col0=None, res=False, rp=0):
-    """every (mi, nt, tiles_per_range) the kernel accepts for this GEMM (160 KiB of LDS: ring + vectors + LoRA-B rows), thinned
-    to a handful"""
+    """every (mi, nt, tiles_per_range, waves) the kernel accepts for this GEMM (160 KiB of LDS: ring + vectors + LoRA-B rows),
+    thinned to a handful"""
     out = []
-    for mi in ((1, 2) if K <= 384 else (1,)):
-        for nt in ((64,) if geglu else (32, 64)):
-            if vt_col0 is not None and vt_col0 % nt:
-                continue
-            nti = N // nt
-            stage = nt * K * 2 + (64 * mi * nt * 2 if res else 0)
-            tprs = [t for t in range(1, nti + 1) if nti % t == 0 and t * nt <= 512
-                    and min(t, 3) * stage + 2 * 64 * mi * 4 + 2 * t * nt * 4 + t * nt * rp * 2 <= 160 * 1024]
-            if not tprs:
-                continue
-            for tpr in sorted({tprs[0], tprs[len(tprs) // 2], tprs[-1]}):
-                out.append((mi, nt, tpr))
+    for nw in (4, 8):
+        for mi in ((1, 2) if (K <= 384 and nw == 4) else (1,)):
+            for nt in ((64,) if geglu else (32, 64)):
+                if vt_col0 is not None and vt_col0 % nt:
+                    continue
+                nti = N // nt
+                bm = 16 * mi * nw
+                stage = nt * K * 2 + (bm * nt * 2 if res else 0)
+                tprs = [t for t in range(1, nti + 1) if nti % t == 0 and t * nt <= 512
+                        and min(t, 3) * stage + 2 * bm * 4 + 2 * t * nt * 4 + t * nt * rp * 2 <= 160 * 1024]
+                if not tprs:
+                    continue
+                for tpr in sorted({tprs[0], tprs[len(tprs) // 2], tprs[-1]}):
+                    out.append((mi, nt, tpr, nw))
     return out
 
 
@@ -185,6 +187,40 @@ def test_geglu_layernorm_folded(ops, labels, M, C, nparts):
     close(ops.linear(dv(x), ops.pack_geglu(w.to(DEV), b.to(DEV))), h2[:, :4 * C] * F.gelu(h2[:, 4 * C:]), rtol=2e-2)
     ops.PGEMM_CFG.clear()
     assert all(l[0].startswith("pgemm_") for l in labels), [l[0] for l in labels]
+
+
+def test_cold_launches_are_deterministic(ops):
+    """Race screen.  Every operand of the kernel reaches LDS asynchronously (LDS-DMA ring, column vectors, LoRA-B rows) behind
+    counted waits and barriers; a read that beats its data shows up only when the LDS still holds something else.  So: two different
+    problems launched alternately from an idle GPU (each launch finds the other's bytes in LDS), every result compared bit for bit
+    with that problem's first result.  (An earlier form of the kernel failed this once in ~100 launches.)"""
+    g = torch.Generator().manual_seed(9)
+    B, N, C = 2, 1000, 256
+    M = B * N
+    probs = []
+    for k in range(2):
+        x = dv(torch.randn(M, C, generator=g) * 1.7 + 0.4)
+        pw = ops.pack_linear_ln((torch.randn(3 * C, C, generator=g) / 16).to(DEV), torch.randn(3 * C, generator=g).to(DEV),
+                                (torch.randn(C, generator=g) * 0.3 + 1).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV))
+        ops.attach_lora(pw, [(i * C, C, (torch.randn(4, C, generator=g) / 4).to(DEV), (torch.randn(C, 4, generator=g) * 0.05).to(DEV), 1.5)
+                             for i in range(3)])
+        probs.append((x, pw, _ln_parts(ops, x.float().cpu(), 4)))
+    key = (M, 3 * C, C, "vl32")
+    for cfg in [(2, 32, 1, 4), (1, 32, 1, 4), (2, 32, 6, 4), (2, 64, 3, 4), (1, 64, 1, 4), (1, 32, 1, 8), (1, 32, 6, 8), (1, 64, 3, 8)]:
+        ops.PGEMM_CFG[key] = cfg
+        first = [None, None]
+        for rep in range(60):
+            k = rep & 1
+            x, pw, lp = probs[k]
+            vt = torch.zeros(B, C, N, dtype=torch.bfloat16, device=DEV)
+            torch.cuda.synchronize()
+            qk = ops.conv(x.view(B, 1, N, C), pw, vt=vt, vt_col0=2 * C, vt_ld=N, vt_batch_stride=C * N, ln_parts=lp)
+            got = (qk.clone(), vt)
+            if first[k] is None:
+                first[k] = got
+            else:
+                assert torch.equal(got[0], first[k][0]) and torch.equal(got[1], first[k][1]), (cfg, rep)
+    ops.PGEMM_CFG.clear()
 
 
 def test_matches_the_convolution_kernel_it_replaces(ops):

@@ -1,0 +1,63 @@
+import math, sys, os, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audioldm_with_lora_amd import ops
+DEV = "cuda"
+bf = lambda x: x.to(torch.bfloat16).float()
+dv = lambda t: t.to(torch.bfloat16).to(DEV)
+def run(B, N, C, r, nparts, cfg, reps, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    M = B * N
+    x = bf(torch.randn(M, C, generator=g) * 1.7 + 0.4)
+    w = bf(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+    b = torch.randn(3 * C, generator=g)
+    gm, bt = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    xn = F.layer_norm(x, (C,), gm, bt, 1e-5)
+    want = xn @ w.t() + b
+    pw = ops.pack_linear_ln(w.to(DEV), b.to(DEV), gm.to(DEV), bt.to(DEV))
+    parts = []
+    for i in range(3 if r else 0):
+        A = bf(torch.randn(r, C, generator=g) / r)
+        Bm = bf(torch.randn(C, r, generator=g) * 0.05)
+        want[:, i * C:(i + 1) * C] += 1.5 * (xn @ A.t()) @ Bm.t()
+        parts.append((i * C, C, A.to(DEV), Bm.to(DEV), 1.5))
+    ops.attach_lora(pw, parts)
+    xs = x.view(M, nparts, C // nparts)
+    lp = torch.stack([xs.sum(2), (xs * xs).sum(2)], dim=2).contiguous().to(DEV)
+    npad = (N + 7) // 8 * 8
+    ops.PGEMM_CFG[(M, 3 * C, C, "v" + (f"l{pw.Rp}" if pw.Rp else ""))] = cfg
+    xd = dv(x)
+    import ctypes
+    from audioldm_with_lora_amd import _lib
+    lib = _lib.load()
+    lib.aldm_pgemm_set_diag.argtypes = [ctypes.c_void_p]
+    dbuf = torch.zeros(128, dtype=torch.int64, device=DEV)
+    lib.aldm_pgemm_set_diag(dbuf.data_ptr())
+    counts = []
+    nbad, worst, first = 0, 0.0, None
+    wantd = want.to(DEV)
+    base = (xn @ w.t() + b).to(DEV)                       # the result without any LoRA term
+    for rep in range(reps):
+        vt = torch.zeros(B, C, npad, dtype=torch.bfloat16, device=DEV)
+        torch.cuda.synchronize()                            # every launch from an idle GPU
+        qk = ops.conv(xd.view(B, 1, N, C), pw, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad, ln_parts=lp).view(M, 2 * C)
+        got = torch.cat([qk.float(), vt[:, :, :N].permute(0, 2, 1).reshape(M, C).float()], 1)
+        c = dbuf[48:52].tolist()
+        if any(c):
+            counts.append((rep, c))
+            dbuf.zero_()
+        err = (got - wantd).abs()
+        bad = ~(err <= 0.064 + 2e-2 * wantd.abs())
+        if bool(bad.any()):
+            nbad += 1
+            if first is None:
+                idx = bad.nonzero()[:6]
+                first = (rep, bad.any(1).nonzero().flatten().tolist()[:4], bad.any(0).nonzero().flatten().tolist()[:8],
+                         [(round(float(got[i, j]), 3), round(float(wantd[i, j]), 3), round(float(base[i, j]), 3)) for i, j in idx.tolist()])
+        worst = max(worst, float(err.max()))
+    print(os.environ.get("ALDM_LIB", "default")[-9:], cfg, f"M{M} C{C} r{r}: {nbad}/{reps} bad launches, worst err {worst:.3f}", first, "LDS mismatches [c_n, s_n, LB, W] per launch:", counts[:6], len(counts), flush=True)
+    lib.aldm_pgemm_set_diag(None)
+for cfg in [(2, 32, 1), (1, 32, 1), (2, 64, 1), (2, 32, 2), (1, 64, 3)]:
+    run(2, 1000, 256, 4, 4, cfg, 400)
+run(3, 252, 384, 4, 6, (2, 32, 1), 300)
+run(3, 252, 384, 4, 6, (1, 32, 2), 300)

@@ -1,0 +1,140 @@
+"""Launch-shape sweep for aldm_pgemm (csrc/pgemm.hip): every valid (rows per workgroup, tile width, tiles per range) of every
+projection GEMM of the UNet's transformer blocks, timed inside a replayed hipGraph of `reps` launches over rotating buffers (the
+kernels then run back to back as in the captured denoise step).  Writes audioldm_with_lora_amd/pgemm_gfx950.json, which ops.py
+loads into PGEMM_CFG.
+usage: python tools/tune_pgemm.py [--batch 8] [--reps 24] [--write]"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audioldm_with_lora_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def make_case(kind, M, N, K, B, nbuf=3):
+    """operands of one GEMM as the UNet issues it; returns (key, run(i)) with run launching on buffer set i"""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xs = [torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV) for _ in range(nbuf)]
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    gm, bt = (torch.randn(K, generator=g) * 0.3 + 1).to(DEV), (torch.randn(K, generator=g) * 0.2).to(DEV)
+    lora = lambda n0, n: (n0, n, (torch.randn(4, K, generator=g) / 4).to(DEV), (torch.randn(n, 4, generator=g) * 0.05).to(DEV), 1.0)
+    parts = torch.randn(M, 4, 2, generator=g).abs().to(DEV)
+    parts[:, :, 1] = parts[:, :, 0] ** 2 + K / 4.0
+    if kind == "proj_in":
+        pw = ops.pack_linear(w, b)
+        return "", lambda i: ops.linear(xs[i], pw, rowstats=True)
+    if kind == "out":
+        pw = ops.pack_linear(w, b)
+        ops.attach_lora(pw, [lora(0, N)])
+        res = [torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) for _ in range(nbuf)]
+        return f"rl{pw.Rp}", lambda i: ops.linear(xs[i], pw, res=res[i], rowstats=True)
+    if kind == "qkv":
+        C = N // 3
+        pw = ops.pack_linear_ln(w, None, gm, bt)
+        ops.attach_lora(pw, [lora(j * C, C) for j in range(3)])
+        n = M // B
+        npad = (n + 7) // 8 * 8
+        vts = [torch.zeros(B, C, npad, dtype=torch.bfloat16, device=DEV) for _ in range(nbuf)]
+        return f"vl{pw.Rp}", lambda i: ops.conv(xs[i].view(B, 1, n, K), pw, vt=vts[i], vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad, ln_parts=parts)
+    if kind == "ff1":
+        pw = ops.pack_linear_ln(w, b, gm, bt, geglu=True)
+        return "g", lambda i: ops.linear(xs[i], pw, ln_parts=parts)
+    raise ValueError(kind)
+
+
+def configs(kind, M, N, K):
+    out = []
+    for nw in (4, 8):
+        for mi in ((1, 2) if (K <= 384 and nw == 4) else (1,)):
+            for nt in ((64,) if kind == "ff1" else (32, 64)):
+                if kind == "qkv" and (2 * N // 3) % nt:
+                    continue
+                nti = N // nt
+                res = kind == "out"
+                rp = 32 if kind in ("out", "qkv") else 0
+                bm = 16 * mi * nw
+                stage = nt * K * 2 + (bm * nt * 2 if res else 0)
+                for t in range(1, nti + 1):
+                    if nti % t or t * nt > 512:
+                        continue
+                    if kind in ("proj_in", "out") and nti // t > 16:
+                        continue
+                    if min(t, 3) * stage + 2 * bm * 4 + 2 * t * nt * 4 + t * nt * rp * 2 > 160 * 1024:
+                        continue
+                    if math.ceil(M / bm) * (nti // t) > 2048:
+                        continue
+                    out.append((mi, nt, t, nw))
+    return out
+
+
+def time_cfg(run, reps, nbuf):
+    run(0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(reps):
+            run(i % nbuf)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, nargs="+", default=[8, 2])
+    ap.add_argument("--reps", type=int, default=24)
+    ap.add_argument("--write", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    table = {}
+    nbuf = 3
+    for B in a.batch:
+        levels = [(256, 1000), (384, 252), (640, 64)]
+        for C, n in levels:
+            M = B * n
+            for kind, N in (("proj_in", C), ("qkv", 3 * C), ("out", C), ("ff1", 8 * C)):
+                if a.only and a.only != kind:
+                    continue
+                sfx, run = make_case(kind, M, N, C, B, nbuf)
+                key = (M, N, C, sfx)
+                ops.PGEMM_CFG.pop(key, None)
+                base = time_cfg(run, a.reps, nbuf)
+                res = []
+                for cfg in configs(kind, M, N, C):
+                    ops.PGEMM_CFG[key] = cfg
+                    try:
+                        res.append((time_cfg(run, a.reps, nbuf), cfg))
+                    except _lib.AldmError as e:
+                        print(f"  {cfg}: {e}", flush=True)
+                ops.PGEMM_CFG.pop(key, None)
+                res.sort()
+                os.environ["ALDM_NO_PGEMM"] = "1"
+                ops.PGEMM = False
+                old = time_cfg(run, a.reps, nbuf)
+                ops.PGEMM = True
+                print(f"{kind:8s} M{M} N{N} K{C}: plan {base:6.2f} us | igemm {old:6.2f} us | best " +
+                      "  ".join(f"{c} {t:5.2f}" for t, c in res[:5]) + f" | worst {res[-1][1]} {res[-1][0]:5.2f}", flush=True)
+                # (a GEMM that measures faster on the convolution kernel stays there: [0, 0, 0, 0])
+                table["|".join(map(str, key))] = list(res[0][1]) if res[0][0] <= 0.98 * old else [0, 0, 0, 0]
+    if a.write:
+        path = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "pgemm_gfx950.json")
+        with open(path, "w") as f:
+            json.dump({"device": "MI355X gfx950", "format": "M|N|K|kind -> [mi, nt, tiles_per_range, waves]; [0, 0, 0, 0] = keep aldm_igemm", "pgemm": table}, f, indent=0, sort_keys=True)
+        print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
