@@ -143,6 +143,8 @@ PROTOTYPES = {
     "aldm_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_float, C.c_void_p, C.c_void_p]),
     "aldm_cfg_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aldm_ddim_step_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aldm_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
     "aldm_add_noise_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
     "aldm_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),

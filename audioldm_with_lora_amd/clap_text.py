@@ -179,6 +179,19 @@ class ClapTextModelWithProjection(nn.Module):
         Le = min(L, (int(lens.max()) + 7) // 8 * 8)                  # longest caption, 8-token granules
         ids = input_ids[:, :Le].to(dev, torch.int64).contiguous()
         kv_len = lens.to(dev)
+        emb, x, pooled = self.forward_device(ids, kv_len)
+        if not return_dict:
+            return (emb, x)
+        return SimpleNamespace(text_embeds=emb, last_hidden_state=x, pooler_output=pooled)
+
+    @torch.no_grad()
+    def forward_device(self, ids, kv_len):
+        """The launch sequence alone: ids int64 [B, Le] and kv_len int32 [B] already on the device, Le >= every length.  No host
+        synchronisation, so it can sit inside a captured hipGraph (training.LoraTrainer.step_from_batch)."""
+        P, cfg = self.plan(), self.cfg
+        dev = ids.device
+        B, Le = ids.shape
+        C, H, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
         x = ops.embed_layernorm(ids, P.word, P.pos, P.type0, P.emb_ln[0], P.emb_ln[1], eps, cfg["pad_token_id"])
         for lp in P.layers:
             vt = torch.empty(B, C, Le, dtype=torch.bfloat16, device=dev)
@@ -191,7 +204,5 @@ class ClapTextModelWithProjection(nn.Module):
         pooled = ops.linear(first, P.pool, out_act=ACT_TANH)
         t = ops.linear(pooled, P.p1, out_act=ACT_LRELU, out_slope=0.0)                 # ReLU
         emb = ops.linear(t, P.p2, out_f32=True)
-        if not return_dict:
-            return (emb, x.view(B, Le, C))
-        return SimpleNamespace(text_embeds=emb, last_hidden_state=x.view(B, Le, C), pooler_output=pooled)
+        return emb, x.view(B, Le, C), pooled
 

@@ -80,6 +80,52 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, float* __res
   }
 }
 
+// The whole per-step bookkeeping of the replayed DDIM loop as ONE launch behind the UNet: classifier-free guidance + DDIM update
+// (as cfg_ddim_step_kernel), the NEXT step's row of the precomputed time-embedding table gathered into `rowbias`, and the
+// device-side step counter advanced.  Every workgroup reads the counter when it starts; the one that finishes LAST (an
+// agent-scope ticket) writes the new value, so no workgroup can see the counter move under it -- three launches become one.
+__global__ __launch_bounds__(256) void ddim_step_fused_kernel(const float* __restrict__ eps, float* __restrict__ x, int B, long long n, int cfg,
+                                                              float g, const float* __restrict__ coef, int* __restrict__ step_idx,
+                                                              bf16* __restrict__ x_in, const float* __restrict__ table, long long row_elems,
+                                                              float* __restrict__ rowbias, const float* __restrict__ timesteps, int n_steps,
+                                                              float* __restrict__ t_out, unsigned* __restrict__ ticket) {
+  const int cur = step_idx[0];
+  int nxt = cur + 1;
+  if (nxt >= n_steps) nxt = 0;                                // wrap: a replayed graph may run past the schedule (benchmarks)
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * n;
+  if (idx < total) {
+    const float* cf = coef + 4 * cur;
+    const float sa = cf[0], sb = cf[1], sap = cf[2], sbp = cf[3];
+    float e;
+    if (cfg) {
+      const float eu = eps[idx], et = eps[total + idx];
+      e = eu + g * (et - eu);
+    } else {
+      e = eps[idx];
+    }
+    const float xv = x[idx];
+    const float x0 = (xv - sb * e) / sa;
+    const float xn = sap * x0 + sbp * e;
+    x[idx] = xn;
+    if (x_in) {
+      x_in[idx] = (bf16)xn;
+      if (cfg) x_in[total + idx] = (bf16)xn;
+    }
+  }
+  if (table && idx * 4 < row_elems)
+    *reinterpret_cast<f32x4*>(rowbias + idx * 4) = *reinterpret_cast<const f32x4*>(table + (long long)nxt * row_elems + idx * 4);
+  __syncthreads();                                            // every thread of this workgroup has read the counter
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {                              // last workgroup: nobody will read step_idx[0] again in this launch
+      ticket[0] = 0;
+      step_idx[0] = nxt;
+      t_out[0] = timesteps[nxt];
+    }
+  }
+}
+
 __global__ void advance_step_kernel(int* step_idx, const float* __restrict__ timesteps, int n_steps, float* t_out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int i = step_idx[0] + 1;
@@ -194,6 +240,17 @@ extern "C" int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n
   ALDM_CHECK_ARG(eps && x && coef && step_idx && B > 0 && n_per_sample > 0, "cfg_ddim_step: bad args");
   hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3(blocks_for((long long)B * n_per_sample, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg, guidance, coef, step_idx, (bf16*)x_in_bf16);
   return aldm_launch_status("cfg_ddim_step");
+}
+
+extern "C" int aldm_ddim_step_fused(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance, const float* coef,
+                                    int* step_idx, void* x_in_bf16, const float* table, long long row_elems, float* rowbias,
+                                    const float* timesteps, int n_steps, float* t_out, unsigned* ticket, void* stream) {
+  ALDM_CHECK_ARG(eps && x && coef && step_idx && timesteps && t_out && ticket && B > 0 && n_per_sample > 0 && n_steps > 0, "ddim_step_fused: bad args");
+  ALDM_CHECK_ARG(!table || (rowbias && row_elems > 0 && row_elems % 4 == 0), "ddim_step_fused: table needs rowbias and row_elems %% 4 == 0");
+  const long long work = (long long)B * n_per_sample > row_elems / 4 ? (long long)B * n_per_sample : row_elems / 4;
+  hipLaunchKernelGGL(ddim_step_fused_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg,
+                     guidance, coef, step_idx, (bf16*)x_in_bf16, table, table ? row_elems : 0, rowbias, timesteps, n_steps, t_out, ticket);
+  return aldm_launch_status("ddim_step_fused");
 }
 
 extern "C" int aldm_add_noise(const float* x, const float* noise, const float* coef, int B, long long n_per_sample,

@@ -587,7 +587,7 @@ int pg_launch(const PgHost& h, hipStream_t st) {
 // the instantiations the transformer blocks use; anything else is refused (the caller keeps aldm_igemm)
 template <int K, int NT, int MI, int NW>
 int pg_dispatch(const PgHost& a, int rt, int epi, int fl, hipStream_t st) {
-#define PG_CASE(RT_, EPI_, FL_) if (rt == (RT_) && epi == (EPI_) && fl == (FL_)) return pg_launch<K, NT, MI, RT_, EPI_, FL_, NW>(a, st);
+#define PG_CASE(RT_, EPI_, FL_) if constexpr ((RT_) == 0 || K <= 384 || MI == 1) { if (rt == (RT_) && epi == (EPI_) && fl == (FL_)) return pg_launch<K, NT, MI, RT_, EPI_, FL_, NW>(a, st); }
   PG_CASE(0, EPI_STD, 0)                                     // plain linear (+ bias)
   PG_CASE(0, EPI_STD, PG_RSTAT)                              // proj_in: + statistics for norm1
   PG_CASE(0, EPI_STD, PG_RES)
@@ -618,9 +618,9 @@ int pg_dispatch_k(const PgHost& a, int nw, int mi, int nt, int rt, int epi, int 
   if (nw == 4) {
     if (nt == 64 && mi == 1) return pg_dispatch<K, 64, 1, 4>(a, rt, epi, fl, st);
     if (nt == 32 && mi == 1) return pg_dispatch<K, 32, 1, 4>(a, rt, epi, fl, st);
-    if constexpr (K <= 384) {                                 // MI = 2 keeps 64 (96) registers of x per lane; K = 640 would need 160
-      if (nt == 64 && mi == 2) return pg_dispatch<K, 64, 2, 4>(a, rt, epi, fl, st);
-      if (nt == 32 && mi == 2) return pg_dispatch<K, 32, 2, 4>(a, rt, epi, fl, st);
+    if (mi == 2 && (K <= 384 || rt == 0)) {                   // MI = 2: 64 / 96 / 160 registers of x per lane; at K = 640 there is
+      if (nt == 64) return pg_dispatch<K, 64, 2, 4>(a, rt, epi, fl, st);   // no room for the LoRA-A fragments beside them
+      if (nt == 32) return pg_dispatch<K, 32, 2, 4>(a, rt, epi, fl, st);
     }
   } else if (nw == 8) {                                       // two waves per SIMD: one wave's MFMAs run under the other's epilogue
     if (nt == 64 && mi == 1) return pg_dispatch<K, 64, 1, 8>(a, rt, epi, fl, st);
@@ -649,7 +649,7 @@ extern "C" int aldm_pgemm_plan(aldm_pgemm_t* g) {
   int bmi = 0, bnt = 0, btpr = 0, bnw = 0;
   for (int nw = 4; nw <= 8; nw += 4) {
     if (g->waves && g->waves != nw) continue;
-    for (int mi = 1; mi <= ((g->K <= 384 && nw == 4) ? 2 : 1); ++mi) {
+    for (int mi = 1; mi <= (((g->K <= 384 || rt == 0) && nw == 4) ? 2 : 1); ++mi) {
       if (g->mi && g->mi != mi) continue;
       for (int nt = 32; nt <= 64; nt += 32) {
         if ((g->nt && g->nt != nt) || (g->geglu && nt != 64) || (g->vt && g->vt_col0 % nt)) continue;

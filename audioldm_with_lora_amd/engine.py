@@ -42,6 +42,7 @@ class DenoiseEngine:
         self.x_in = [torch.zeros(nbc, height, width, self.C, dtype=torch.bfloat16, device=dev) for _ in range(chains)]
         self.t_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # aldm_ddim_step_fused's last-workgroup ticket (rests at 0)
         self.cls = None
         self.temb = None             # [chains][n_steps, nbc, temb_total] fp32: time-embedding projections of every step
         self.rowbias = None          # [chains][nbc, temb_total] fp32: the current step's row (gathered on the device)
@@ -89,6 +90,7 @@ class DenoiseEngine:
         else:
             for dst, src in zip(self.temb, tabs):
                 dst.copy_(src)
+        self._prime()
 
     def set_latents(self, latents_nchw):
         """latents [B, C, H, W] fp32 (already multiplied by init_noise_sigma = 1)."""
@@ -102,6 +104,13 @@ class DenoiseEngine:
                 self.x_in[i][self.bc:].copy_(xb[sl])
         self.step_idx.zero_()
         self.t_buf.copy_(self.timesteps_f32[:1])
+        self._prime()
+
+    def _prime(self):
+        """The single-chain step gathers the NEXT step's time-embedding row at its end (ops.ddim_step_fused); the row of the
+        step the counter stands at is put in place here, whenever the counter or the table changes outside the graph."""
+        if self.temb is not None and self.chains == 1:
+            ops.gather_row(self.temb[0], self.step_idx, self.rowbias[0])
 
     def _chain_step(self, i):
         ops.gather_row(self.temb[i], self.step_idx, self.rowbias[i])
@@ -110,7 +119,11 @@ class DenoiseEngine:
 
     def _one_step(self):
         if self.chains == 1:
-            self._chain_step(0)
+            # one chain: guidance + DDIM update, the next step's time-embedding row and the step counter in ONE launch behind the UNet
+            eps = self.unet.forward_nhwc(self.x_in[0], self.t_buf, self.cls[0], rowbias=self.rowbias[0])
+            ops.ddim_step_fused(eps, self.x, self.cfg, self.g, self.coef, self.step_idx, self.x_in[0], self.temb[0], self.rowbias[0],
+                                self.timesteps_f32, self.t_buf, self.ticket)
+            return
         else:                                   # fork / join: under capture these become parallel graph branches
             cur = torch.cuda.current_stream()
             if self._side is None:
@@ -143,6 +156,7 @@ class DenoiseEngine:
                 self._one_step()
         for dst, src in zip([self.x] + self.x_in + [self.step_idx, self.t_buf], [saved[0]] + saved[1] + [saved[2], saved[3]]):
             dst.copy_(src)
+        self._prime()
         torch.cuda.synchronize()
 
     def step(self):

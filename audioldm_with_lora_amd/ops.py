@@ -906,6 +906,18 @@ def cfg_ddim_step(eps, x, cfg, guidance, coef, step_idx, x_in):
                                                           _stream())), "aldm_cfg_ddim_step")
 
 
+def ddim_step_fused(eps, x, cfg, guidance, coef, step_idx, x_in, table, rowbias, timesteps_f32, t_out, ticket):
+    """cfg_ddim_step + gather_row(next step) + advance_step as one launch (aldm_ddim_step_fused)."""
+    B = x.shape[0]
+    n = x.numel() // B
+    row = table[0].numel() if table is not None else 0
+    assert ticket.dtype == torch.int32 and step_idx.dtype == torch.int32
+    check(_launch("ddim_step_fused", 6.0 * x.numel(), (4.0 * (2 if cfg else 1) + 8.0 + 2.0 * (2 if cfg else 1)) * x.numel() + 8.0 * row,
+                  lambda: _lib.load().aldm_ddim_step_fused(_p(eps), _p(x), B, n, int(cfg), guidance, _p(coef), _p(step_idx), _p(x_in), _p(table),
+                                                           row, _p(rowbias), _p(timesteps_f32), timesteps_f32.numel(), _p(t_out), _p(ticket),
+                                                           _stream())), "aldm_ddim_step_fused")
+
+
 def add_noise(x, noise, coef):
     _require_gpu(x)
     B = x.shape[0]

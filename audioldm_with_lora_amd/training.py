@@ -650,10 +650,63 @@ class LoraTrainer:
         self.graph.replay()
         return f.grads[f.n:]
 
+    def step_from_batch(self, vae, text_encoder, batch, noise, timesteps, sample_noise):
+        """The reference's WHOLE loop body for one collate_fn batch [REF script/train/train_audioldm_lora.py:495-565]:
+            latents = vae.encode(batch["log_mel_spec"]).latent_dist.sample() * vae.config.scaling_factor
+            prompt_embeds = normalize(text_encoder(input_ids, attention_mask).text_embeds)
+            noisy = add_noise(latents, noise, timesteps);  pred = unet(noisy, t, class_labels=prompt_embeds);  mse;  backward
+        as ONE captured hipGraph per (batch shape, caption-length bucket), then the flat all-reduce and AdamW as in step().
+        sample_noise [B, 8, H/4, 16] is the N(0, 1) draw of latent_dist.sample() (passed in so that the graph has no RNG state)."""
+        dev = self.dev
+        ids, mask = batch["input_ids"].squeeze(1), batch["attention_mask"].squeeze(1)
+        lens = text_encoder._lengths(ids, mask)                  # host-side validation of the padding mask (CPU tensors)
+        Le = min(ids.shape[1], (int(lens.max()) + 63) // 64 * 64)   # 64-token buckets: few distinct graphs
+        args = (batch["log_mel_spec"].to(dev, torch.float32).contiguous(), ids[:, :Le].to(dev, torch.int64).contiguous(),
+                lens.to(dev), sample_noise.to(dev, torch.float32).contiguous(), noise.to(dev, torch.float32).contiguous(),
+                timesteps.to(dev, torch.int64).contiguous())
+        sf = float(vae.config.scaling_factor)
+
+        def body(mel, ids_d, kv_len, eps, nz, ts):
+            mom = ops.nhwc_to_nchw_f32(vae.encode_nhwc(ops.nchw_to_nhwc(mel)))
+            lat = ops.gaussian_sample(mom, eps) * sf
+            emb = torch.nn.functional.normalize(text_encoder.forward_device(ids_d, kv_len)[0], dim=-1)
+            self._fwd_bwd(lat, nz, ts, emb)
+
+        f = self.flat
+        key = tuple(tuple(a.shape) for a in args)
+        if not self.use_graph:
+            body(*args)
+        else:
+            if not hasattr(self, "_body_graphs"):
+                self._body_graphs, self._body_eager = {}, {}
+            ent = self._body_graphs.get(key)
+            if ent is None:
+                n = self._body_eager.get(key, 0) + 1
+                self._body_eager[key] = n
+                if n <= 2:
+                    body(*args)                                # two eager warm-up steps (code objects, workspace sizes)
+                else:
+                    static = tuple(a.clone() for a in args)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        body(*static)
+                    self.tnb.upload()
+                    self._body_graphs[key] = (g, static)
+                    g.replay()
+            else:
+                g, static = ent
+                for dst, src in zip(static, args):
+                    dst.copy_(src)
+                g.replay()
+        return self._apply_update(f.grads[f.n:])
+
     def step(self, latents, noise, timesteps, prompt_embeds):
         """One optimisation step; returns the (all-rank mean) loss as a device tensor."""
+        return self._apply_update(self.loss_and_grads(latents, noise, timesteps, prompt_embeds))
+
+    def _apply_update(self, loss):
         f = self.flat
-        loss = self.loss_and_grads(latents, noise, timesteps, prompt_embeds)
         if self.dist and self.world > 1:
             self.dist.all_reduce(f.grads)                         # ONE flat all-reduce: every LoRA grad + the loss slot
         self.step_count += 1

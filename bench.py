@@ -85,8 +85,14 @@ def trace_replays(engine, reps=6):
         evs.sort(key=lambda e: e.time_range.start)
         # cut the stream into replays at the step's first kernel (gather_row); keep the complete ones (the tracer may drop or add
         # a few events at the edges of its window)
-        starts = [i for i, e in enumerate(evs) if "gather_row_kernel" in e.name]
-        segs = [evs[a:b] for a, b in zip(starts, starts[1:] + [len(evs)])]
+        # (the step's LAST kernel is the fused guidance / DDIM / counter launch; with several chains the step still opens with gather_row)
+        ends = [i for i, e in enumerate(evs) if "ddim_step_fused_kernel" in e.name]
+        if ends:
+            starts = [0] + [i + 1 for i in ends[:-1]]
+            segs = [evs[a:b + 1] for a, b in zip(starts, ends)][1:]      # the first segment may be cut by the tracer's window
+        else:
+            starts = [i for i, e in enumerate(evs) if "gather_row_kernel" in e.name]
+            segs = [evs[a:b] for a, b in zip(starts, starts[1:] + [len(evs)])]
         if not segs:
             print(f"[bench] kernel trace: no replay boundary among {len(evs)} device events", file=sys.stderr)
             return None, None
@@ -325,7 +331,91 @@ def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
     return {"metric": "lora_train_clips_per_sec", "value": round(world * batch * steps / dt, 3), "unit": "10.24s-clips/s",
             "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "per_gpu_batch": batch, "lora_rank": rank_lora,
             "lora_params": 112640 * rank_lora, "final_loss": round(final, 5),
-            "collective": "1 flat fp32 all-reduce/step (RCCL)" if world > 1 else "none"}
+            "collective": "1 flat fp32 all-reduce/step (RCCL)" if world > 1 else "none",
+            "dtype": TRAIN_DTYPE, "gradient_tolerance": TRAIN_TOL}
+
+
+def bench_variant(unet, batch, guidance, steps, warmup, fp8, rank_lora, k1=False):
+    """A secondary denoise-loop leg on the same UNet (own engine / graph): ms per step, optionally the K1 sites."""
+    from audioldm_with_lora_amd.engine import DenoiseEngine
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    unet.attention_fp8 = fp8
+    try:
+        eng = DenoiseEngine(unet, DDIMScheduler(), batch, 250, 16, 200 if steps > 50 else 50, guidance)
+        lat, pe, ne = synth_inputs(batch, 250, 16, seed_off=7)
+        eng.set_condition(pe, ne)
+        eng.set_latents(lat)
+        eng.capture()
+        for _ in range(warmup):
+            eng.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(eng.x).all(), "latents diverged"
+        out = {"ms_per_step": round(dt / steps * 1e3, 4), "denoise_steps_per_sec": round(steps / dt, 2), "steps": steps,
+               "per_gpu_batch": batch, "unet_batch": 2 * batch if guidance > 1.0 else batch, "guidance_scale": guidance}
+        if k1:
+            kernels, _ = trace_replays(eng)
+            ev_rows = launch_rows(eng)
+            rows = join_trace(ev_rows, kernels) if kernels else None
+            if rows is None:
+                rows = [(l, f, b, e, s, e, [(l.split("|")[0], e)]) for l, f, b, e, s in ev_rows]
+            out["k1_sites"] = [{k: v for k, v in site.items() if k in ("site", "us_per_module", "parts_us", "tflops", "frac", "bound")}
+                               for site in k1_sites(rows, 2 * batch, rank_lora)]
+        eng.graph = None
+        return out
+    finally:
+        unet.attention_fp8 = False
+
+
+def bench_loop_body(steps=6, warmup=4, batch=8, rank_lora=8):
+    """The reference's whole loop body per collate_fn batch [REF script/train/train_audioldm_lora.py:495-565]: log-mel [8,1,1024,64]
+    -> vae.encode -> latent_dist.sample() * scaling_factor; token ids (captions of 8..64 tokens padded to 512) -> CLAP text tower ->
+    normalize; add_noise -> UNet fwd -> MSE -> bwd -> AdamW -- as ONE captured hipGraph (LoraTrainer.step_from_batch)."""
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    from audioldm_with_lora_amd.script.train import synthetic_batch
+    from audioldm_with_lora_amd.training import LoraTrainer
+    from audioldm_with_lora_amd.unet import UNet2DConditionModel
+    from audioldm_with_lora_amd.vae import AutoencoderKL
+    torch.manual_seed(1234)
+    unet = UNet2DConditionModel()
+    get_peft_model(unet, LoraConfig(r=rank_lora, lora_alpha=rank_lora, init_lora_weights="gaussian",
+                                    target_modules=["to_q", "to_k", "to_v", "to_out.0"]))
+    unet.cuda()
+    vae = AutoencoderKL().requires_grad_(False).cuda()
+    clap = ClapTextModelWithProjection().requires_grad_(False).cuda()
+    tr = LoraTrainer(unet, DDIMScheduler(), lr=1e-5, weight_decay=1e-5, max_train_steps=97000)
+    g = torch.Generator().manual_seed(21)
+    b = synthetic_batch(batch, g, vocab=clap.cfg["vocab_size"])
+    noise = torch.randn(batch, 8, 256, 16, generator=g)
+    eps = torch.randn(batch, 8, 256, 16, generator=g)
+    t = torch.randint(0, 1000, (batch,), generator=g)
+    for _ in range(warmup):
+        tr.step_from_batch(vae, clap, b, noise, t, eps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step_from_batch(vae, clap, b, noise, t, eps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    final = float(loss)
+    assert final == final
+    del tr, unet, vae, clap
+    torch.cuda.empty_cache()
+    return {"what": "mel -> VAE encode -> sample, ids -> CLAP text tower -> normalize, add_noise -> UNet fwd -> MSE -> bwd -> AdamW; "
+                    "one captured hipGraph per step [REF train:495-565]",
+            "ms_per_step": round(dt / steps * 1e3, 2), "clips_per_sec": round(batch * steps / dt, 2), "per_gpu_batch": batch,
+            "lora_rank": rank_lora, "steps": steps, "final_loss": round(final, 5), "dtype": TRAIN_DTYPE}
+
+
+TRAIN_DTYPE = ("bf16 activations and activation gradients, fp32 accumulation / statistics / loss, fp32 LoRA master weights, gradients "
+               "and AdamW (the reference trains in fp32 [REF train:329,389]: this leg is a mixed-precision number)")
+TRAIN_TOL = "flat LoRA gradient vs fp32 autograd: rel. L2 <= 6e-2 (tests/test_gpu_train_fullsize.py); AdamW vs torch.optim.AdamW 2e-6"
 
 
 def main():
@@ -409,6 +499,13 @@ def main():
     if not args.no_train and rank == 0 and not args.fp8_attention and args.chains in (None, 1):
         pipe_t = bench_pipeline(unet, args.batch, 10.0, NSTEPS, G, seed_off=100 * rank)
     eng.graph = None
+    fp8_leg = b1_leg = b1_pipe = body_leg = None
+    if not args.no_train and rank == 0 and world == 1 and not args.fp8_attention and args.chains in (None, 1):
+        # BASELINE config 5's per-GPU work: the same loop with e4m3 attention operands (prompt-sharded: no collective)
+        fp8_leg = bench_variant(unet, args.batch, G, 50, 5, True, args.rank, k1=True)
+        # what the reference's entry points run: one prompt, 50 steps, guidance 5.0 [REF script/inference/generate_audio.py:47-52]
+        b1_leg = bench_variant(unet, 1, 5.0, 50, 5, False, args.rank)
+        b1_pipe = bench_pipeline(unet, 1, 10.0, 50, 5.0, seed_off=3)
     train = train16 = None
     if not args.no_train:
         torch.cuda.empty_cache()
@@ -417,6 +514,7 @@ def main():
         train = bench_train(world, rank, rank_lora=(8 if world == 1 else 16))
         if world == 1:
             train16 = bench_train(world, rank, steps=4, warmup=3, rank_lora=16)
+            body_leg = bench_loop_body()
     if rank == 0:
         agg = aggregate(rows)
         total_us = sum(v["us"] for v in agg.values())
@@ -473,8 +571,23 @@ def main():
             out["end_to_end"] = {"clips_per_sec": round(world * args.batch / call_s, 3), "clip_seconds": 10.0, "ddim_steps": NSTEPS,
                                  "pipe_call_ms": round(call_s * 1e3, 1), "first_call_ms_incl_capture": round(first_s * 1e3, 1),
                                  "vae_decode_ms": round(legs["vae_decode_ms"], 2), "vocoder_ms": round(legs["vocoder_ms"], 2),
+                                 # 654.0 / 1002.8 GFLOP per 10 s clip; fraction of the dense bf16 MFMA peak
+                                 "vae_frac": round(args.batch * 654.0e9 / (legs["vae_decode_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                 "vocoder_frac": round(args.batch * 1002.8e9 / (legs["vocoder_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                  "note": "pipe_call_ms = one timed AudioLDMPipeline.__call__ (prompt embeddings + noise in, host audio "
                                          "out): set_condition + 200 graph replays + VAE decode + vocoder + D2H"}
+        if fp8_leg is not None:
+            fp8_leg["what"] = ("BASELINE config 5 per GPU: the timed loop with fp8 (OCP e4m3) Q / K / V / P attention operands, fp32 accumulation; "
+                               "a precision variant, not a faster one (compare ms_per_step with the headline)")
+            fp8_leg["tolerance"] = "full-width UNet vs fp32 oracle rel. L2 <= 6e-2 (tests/test_gpu_unet.py)"
+            out["fp8"] = fp8_leg
+        if b1_leg is not None:
+            call_s, first_s, _ = b1_pipe
+            b1_leg.update({"what": "generate_audio.py's call: 1 prompt, 50 DDIM steps, guidance 5.0, 10 s [REF script/inference/generate_audio.py:47-52]",
+                           "pipe_call_ms": round(call_s * 1e3, 1), "first_call_ms_incl_capture": round(first_s * 1e3, 1)})
+            out["infer_b1"] = b1_leg
+        if body_leg is not None:
+            out["train_loop_body"] = body_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, H, W, args.rank)
         print(json.dumps(out))

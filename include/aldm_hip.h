@@ -293,6 +293,13 @@ int aldm_f32_to_bf16(const float* x, long long n, float mul, void* y, void* stre
    x (fp32, [B][n]) is updated in place; x_in (bf16, [2B][n] if cfg else [B][n]) receives the next UNet input. */
 int aldm_cfg_ddim_step(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance,
                        const float* coef, const int* step_idx, void* x_in_bf16, void* stream);
+/* aldm_cfg_ddim_step + aldm_gather_row (of the NEXT step's row of `table` [n_steps][row_elems] into rowbias; table may be NULL)
+   + aldm_advance_step as ONE launch at the end of a replayed denoise step: the workgroup that finishes last (ticket: one zeroed
+   device word, left zero again) moves the counter, so every workgroup of the launch reads the same step index.
+   AudioLDMPipeline.__call__'s loop body bookkeeping [REF script/inference/generate_audio.py:47-52]. */
+int aldm_ddim_step_fused(const float* eps, float* x, int B, long long n_per_sample, int cfg, float guidance, const float* coef,
+                         int* step_idx, void* x_in_bf16, const float* table, long long row_elems, float* rowbias,
+                         const float* timesteps, int n_steps, float* t_out, unsigned* ticket, void* stream);
 /* measurement aid: keeps `stream` busy for ~us microseconds so that later launches queue up behind it (bench.py) */
 int aldm_sleep_us(int us, void* stream);
 /* device-side loop counter for graph replay: step_idx[0] = (step_idx[0] + 1) mod n_steps ; t_out[0] = timesteps[step_idx[0]] */

@@ -88,3 +88,36 @@ def test_guidance_one_equals_unconditional_path_and_linearity_of_step():
     c = coef[17].cpu()
     want = c[2] * ((x.cpu() - c[1] * e[2:].cpu()) / c[0]) + c[3] * e[2:].cpu()
     torch.testing.assert_close(xb.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_step_bookkeeping_equals_the_three_launches_it_replaces():
+    """aldm_ddim_step_fused = cfg_ddim_step + gather_row(next step) + advance_step, bit for bit, over a whole (wrapping) schedule:
+    the counter moves once per launch, after every workgroup has read it."""
+    from audioldm_with_lora_amd import ops
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    s = DDIMScheduler()
+    n_steps = 7
+    s.set_timesteps(n_steps)
+    coef = s.coefficient_table().cuda()
+    ts = s.timesteps.to(torch.float32).cuda()
+    g = torch.Generator().manual_seed(3)
+    B, row = 4, 8320 * 8                                            # the bench shape: 4 x 250 x 16 x 8 latents, 8 x 8320 row
+    x0 = torch.randn(B, 250, 16, 8, generator=g).cuda()
+    table = torch.randn(n_steps, row, generator=g).cuda()
+    xa, xb = x0.clone(), x0.clone()
+    xin_a = torch.zeros(2 * B, 250, 16, 8, dtype=torch.bfloat16, device="cuda")
+    xin_b = torch.zeros_like(xin_a)
+    ia, ib = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ta, tb = ts[:1].clone(), ts[:1].clone()
+    rb_a, rb_b = torch.empty(row, device="cuda"), torch.empty(row, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.gather_row(table, ib, rb_b)                                 # the engine primes the first row outside the graph
+    for step in range(2 * n_steps + 3):
+        e = torch.randn(2 * B, 250, 16, 8, generator=g).cuda()
+        ops.gather_row(table, ia, rb_a)
+        assert torch.equal(rb_a, rb_b), step                        # what the UNet of this step would read
+        ops.cfg_ddim_step(e, xa, True, 2.5, coef, ia, xin_a)
+        ops.advance_step(ia, ts, ta)
+        ops.ddim_step_fused(e, xb, True, 2.5, coef, ib, xin_b, table, rb_b, ts, tb, ticket)
+        assert torch.equal(xa, xb) and torch.equal(xin_a, xin_b) and int(ia) == int(ib) == (step + 1) % n_steps
+        assert torch.equal(ta, tb) and int(ticket) == 0

@@ -54,7 +54,7 @@ def shapes_for(K, N, geglu=False, vt_col0=None, res=False, rp=0):
     thinned to a handful"""
     out = []
     for nw in (4, 8):
-        for mi in ((1, 2) if (K <= 384 and nw == 4) else (1,)):
+        for mi in ((1, 2) if ((K <= 384 or rp == 0) and nw == 4) else (1,)):
             for nt in ((64,) if geglu else (32, 64)):
                 if vt_col0 is not None and vt_col0 % nt:
                     continue

@@ -66,3 +66,50 @@ def test_encode_batch_matches_oracle():
     assert got_lat.shape == want_lat.shape == (2, 8, 16, 16)
     assert rel(got_lat, want_lat) < 3e-2
     assert rel(got_emb, want_emb) < 3e-2
+
+
+def test_whole_loop_body_as_one_graph_equals_encoders_then_step():
+    """LoraTrainer.step_from_batch (mel -> VAE encode -> sample -> CLAP tower -> normalize -> UNet LoRA step, one captured hipGraph)
+    against the same loop body run piecewise (encode_batch's kernels eagerly, then LoraTrainer.step): same losses, same adapter.
+    [REF script/train/train_audioldm_lora.py:495-565]"""
+    import torch.nn.functional as F
+    from audioldm_with_lora_amd import configs, ops
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    from audioldm_with_lora_amd.script.train import synthetic_batch
+    from audioldm_with_lora_amd.training import LoraTrainer
+    from audioldm_with_lora_amd.unet import UNet2DConditionModel
+    from audioldm_with_lora_amd.vae import AutoencoderKL
+
+    def build(use_graph):
+        torch.manual_seed(11)
+        unet = UNet2DConditionModel(**configs.tiny_unet())
+        unet.requires_grad_(False)
+        get_peft_model(unet, LoraConfig(r=2, lora_alpha=2, target_modules=["to_q", "to_k", "to_v", "to_out.0"], init_lora_weights="gaussian"))
+        vae = AutoencoderKL(**configs.tiny_vae()).requires_grad_(False).cuda()
+        clap = ClapTextModelWithProjection(**dict(configs.tiny_clap_text(), max_position_embeddings=514, projection_dim=64)).requires_grad_(False).cuda()
+        return LoraTrainer(unet.cuda(), DDIMScheduler(), lr=1e-3, max_train_steps=20, use_graph=use_graph), vae, clap
+
+    g = torch.Generator().manual_seed(2)
+    steps = []
+    for _ in range(5):
+        b = synthetic_batch(2, g, vocab=200)
+        b["log_mel_spec"] = b["log_mel_spec"][:, :, :64].contiguous()
+        steps.append((b, torch.randn(2, 8, 16, 16, generator=g), torch.randint(0, 1000, (2,), generator=g), torch.randn(2, 8, 16, 16, generator=g)))
+
+    tr_a, vae_a, clap_a = build(True)
+    la = [float(tr_a.step_from_batch(vae_a, clap_a, b, nz, ts, eps)) for b, nz, ts, eps in steps]     # 2 eager steps, capture, replays
+    assert len(tr_a._body_graphs) == 1
+
+    tr_b, vae_b, clap_b = build(False)
+    lb = []
+    for b, nz, ts, eps in steps:
+        mom = vae_b.encode(b["log_mel_spec"].cuda()).latent_dist.parameters
+        lat = ops.gaussian_sample(mom.float(), eps.cuda()) * vae_b.config.scaling_factor
+        emb = F.normalize(clap_b(input_ids=b["input_ids"].squeeze(1), attention_mask=b["attention_mask"].squeeze(1)).text_embeds, dim=-1)
+        lb.append(float(tr_b.step(lat, nz, ts, emb)))
+    for x, y in zip(la, lb):
+        assert abs(x - y) < 1e-3 * abs(y) + 1e-6, (la, lb)
+    pa, pb = tr_a.flat.params, tr_b.flat.params
+    assert float((pa - pb).norm() / pb.norm()) < 1e-3

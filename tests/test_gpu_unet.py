@@ -115,6 +115,15 @@ def test_full_unet_config2_shape_with_fused_lora_matches_oracle():
         want = pref(x, torch.tensor([996, 501]), class_labels=c)[0]
         got = pmine(x.cuda(), torch.tensor([996, 501]).cuda(), class_labels=c.cuda())[0].float().cpu()
     assert rel_l2(got, want) < 3e-2, rel_l2(got, want)
+    # BASELINE config 5 at its real size: the same full-width UNet + rank-4 LoRA with e4m3 Q / K / V / P attention operands
+    # (the 64-token level then runs its QKV projection on aldm_pgemm / aldm_igemm instead of the fused attn_block64 launch).
+    # Stated tolerance: rel. L2 <= 6e-2 against the fp32 oracle; close to, but not identical with, the bf16-attention result.
+    mine.attention_fp8 = True
+    with torch.no_grad():
+        got8 = pmine(x.cuda(), torch.tensor([996, 501]).cuda(), class_labels=c.cuda())[0].float().cpu()
+    mine.attention_fp8 = False
+    assert torch.isfinite(got8).all() and rel_l2(got8, want) < 6e-2, rel_l2(got8, want)
+    assert not torch.equal(got8, got) and rel_l2(got8, got) < 6e-2
 
 
 def test_batch_independence_and_determinism_at_full_size():

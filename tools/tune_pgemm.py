@@ -52,7 +52,7 @@ def make_case(kind, M, N, K, B, nbuf=3):
 def configs(kind, M, N, K):
     out = []
     for nw in (4, 8):
-        for mi in ((1, 2) if (K <= 384 and nw == 4) else (1,)):
+        for mi in ((1, 2) if ((K <= 384 or kind in ("proj_in", "ff1")) and nw == 4) else (1,)):
             for nt in ((64,) if kind == "ff1" else (32, 64)):
                 if kind == "qkv" and (2 * N // 3) % nt:
                     continue
