@@ -20,6 +20,7 @@ UNET = dict(
     norm_eps=1e-5,
     flip_sin_to_cos=True,
     freq_shift=0,
+    sample_size=128,                  # latent frames of the default clip length (AudioLDMPipeline: audio_length_in_s = None)
 )
 
 VAE = dict(

@@ -401,13 +401,39 @@ class Deferred:
 
 
 DEFERRED_COUNT = 0                                         # diagnostics / tests: how many split-K launches deferred their reduce
-_PENDING = None                                            # the Deferred whose partial tiles currently own the workspace
 
 
-def drop_pending():
-    """Forget a deferred reduce nobody consumed (an exception between producer and consumer): called at the top of a forward."""
-    global _PENDING
-    _PENDING = None
+class _PendingMap(dict):
+    """(device, stream) -> the Deferred whose partial tiles currently own THAT stream's split-K workspace.  The workspace is per
+    (device, stream) (_workspace), so the producer -> consumer hand-over is too: two engines on two streams (or two devices) never
+    see each other's pending reduce."""
+
+    def key(self, t):
+        return (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+
+
+_PENDING_BY_STREAM = _PendingMap()
+
+
+def _pending_get(t):
+    return _PENDING_BY_STREAM.get(_PENDING_BY_STREAM.key(t))
+
+
+def _pending_set(t, d):
+    k = _PENDING_BY_STREAM.key(t)
+    if d is None:
+        _PENDING_BY_STREAM.pop(k, None)
+    else:
+        _PENDING_BY_STREAM[k] = d
+
+
+def drop_pending(t=None):
+    """Forget a deferred reduce nobody consumed (an exception between producer and consumer): called at the top of a forward with
+    that forward's input (its device / current stream); without an argument, every stream's."""
+    if t is None:
+        _PENDING_BY_STREAM.clear()
+    else:
+        _pending_set(t, None)
 
 
 def tensor_of(x):
@@ -433,10 +459,9 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     LayerNorm hand-over (BasicTransformerBlock: h -> LayerNorm -> projection): rowstats=True returns (out, stats), stats fp32
     [M, N / BN, 2] = per-row partial (sum, sum of squares) written by the epilogue; a consumer packed with pack_linear_ln takes
     them as ln_parts= and derives mean / rstd from them -- no LayerNorm launch, no statistics pass in either GEMM's K loop."""
-    global _PENDING
-    if _PENDING is not None:
-        raise _lib.AldmError("conv: a deferred split-K reduce is pending -- its consumer groupnorm() must be the next launch")
     _require_gpu(x)
+    if _pending_get(x) is not None:
+        raise _lib.AldmError("conv: a deferred split-K reduce is pending on this stream -- its consumer groupnorm() must be the next launch")
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
     B, IH, IW, C1 = x.shape
     C2 = 0
@@ -613,11 +638,11 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
 
     def finish():
         # the GroupNorm of gn=: over the partial tiles when the launch deferred its reduce, else over the bf16 output
-        global _PENDING
         if gn is None:
             if eff > 1:
-                _PENDING = Deferred(out, a.workspace, eff, a.bias, a.rowbias, a.rowbias_ld, a.res, (pw, rowbias, res, x3, x4))
-                return _PENDING
+                d = Deferred(out, a.workspace, eff, a.bias, a.rowbias, a.rowbias_ld, a.res, (pw, rowbias, res, x3, x4))
+                _pending_set(out, d)
+                return d
             return (out, stats) if rowstats else out
         gamma, beta, groups, eps, act = gn
         if eff <= 1:
@@ -718,10 +743,9 @@ def linear(x2d: torch.Tensor, pw: PackedW, **kw):
 
 def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     """GroupNorm(+SiLU) over channels-last x (| x2).  x may be a Deferred: its split-K reduce then happens here (and fills x.out)."""
-    global _PENDING
     if isinstance(x, Deferred):
-        if x is not _PENDING:
-            raise _lib.AldmError("groupnorm: this deferred convolution's partial tiles are gone (not the pending one)")
+        if x is not _pending_get(x.out):
+            raise _lib.AldmError("groupnorm: this deferred convolution's partial tiles are gone (not the one pending on this stream)")
         B, H, W, C1 = x.out.shape
         C2 = x2.shape[3] if x2 is not None else 0
         Cg = (C1 + C2) // groups
@@ -733,7 +757,7 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
         check(_launch(f"groupnorm_partials|HW{H * W} C{C1}+{C2} S{x.eff}", 10.0 * n, (4.0 * x.eff + 2.0) * n, lambda: lib.aldm_groupnorm_partials(
             x.ws, x.eff, B, H * W, C1, x.bias, x.rowbias, x.rowbias_ld, x.res, _p(x.out), _p(x2), C2, groups, eps,
             _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm_partials")
-        _PENDING = None
+        _pending_set(x.out, None)
         return y
     _require_gpu(x)
     B, H, W, C1 = x.shape
@@ -1022,7 +1046,6 @@ def _like(buf, like):
 def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True, dx_add=None, dx2_add=None):
     """dx (dx2) of act(group_norm(cat[x, x2])).  dx_add / dx2_add: gradients x / x2 already hold from their other consumers;
     they are added inside the kernel (fresh output tensors, the inputs are not modified)."""
-    global _PENDING
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
     dx = torch.empty_like(x)
@@ -1030,12 +1053,12 @@ def groupnorm_bwd(x, dy, gamma, beta, groups, eps, act, x2=None, need_dx2=True, 
     a1 = _like(dx_add, x) if dx_add is not None else None
     a2 = _like(dx2_add, x2) if (dx2 is not None and dx2_add is not None) else None
     if isinstance(dy, Deferred):                           # dY = partial tiles of the dX convolution launched just before
-        if dy is not _PENDING or dy.bias is not None or dy.rowbias is not None or dy.res is not None:
+        if dy is not _pending_get(dy.out) or dy.bias is not None or dy.rowbias is not None or dy.res is not None:
             raise _lib.AldmError("groupnorm_bwd: deferred dY must be the pending split-K launch, without bias / residual")
         assert tuple(dy.out.shape) == (B, H, W, C1 + C2)
         check(_lib.load().aldm_groupnorm_bwd_partials(_p(x), _p(x2), dy.ws, dy.eff, B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta),
                                                       act, _p(dx), _p(dx2), _p(a1), _p(a2), _stream()), "aldm_groupnorm_bwd_partials")
-        _PENDING = None
+        _pending_set(dy.out, None)
         return dx, dx2
     check(_lib.load().aldm_groupnorm_bwd(_p(x), _p(x2), _p(dy), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act,
                                          _p(dx), _p(dx2), _p(a1), _p(a2), _stream()), "aldm_groupnorm_bwd")

@@ -116,7 +116,9 @@ class AudioLDMPipeline:
             raise NotImplementedError("the reference path uses eta = 0")
         vc = self.vocoder.config
         if audio_length_in_s is None:
-            audio_length_in_s = 128 * self.vae_scale_factor * float(np.prod(vc.upsample_rates)) / vc.sampling_rate
+            # diffusers: unet.config.sample_size * vae_scale_factor * prod(upsample_rates) / sampling_rate
+            inner = getattr(getattr(self.unet, "base_model", None), "model", self.unet)          # a PeftModel wraps the UNet
+            audio_length_in_s = inner.config.sample_size * self.vae_scale_factor * float(np.prod(vc.upsample_rates)) / vc.sampling_rate
         height, n_samples = self.geometry(audio_length_in_s)
         if prompt_embeds is None:
             if prompt is None:

@@ -376,7 +376,8 @@ class UNet2DConditionModel(nn.Module):
                     cross_attention_dim=tuple(raw["cross_attention_dim"]),
                     class_embed_input_dim=raw["projection_class_embeddings_input_dim"],
                     norm_num_groups=raw["norm_num_groups"], norm_eps=raw["norm_eps"],
-                    down_block_types=tuple(raw["down_block_types"]), up_block_types=tuple(raw["up_block_types"]))
+                    down_block_types=tuple(raw["down_block_types"]), up_block_types=tuple(raw["up_block_types"]),
+                    sample_size=raw.get("sample_size", 128))
         m = cls(**over)
         from safetensors.torch import load_file
         m.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")), strict=True)
@@ -478,7 +479,7 @@ class UNet2DConditionModel(nn.Module):
         """x [b, H, W, Cin] bf16 channels-last, t_dev fp32 [1] or [b] (device), class_labels [b, D] bf16.
         rowbias: optional precomputed time-embedding projections [b, temb_total] fp32 (temb_table); t_dev / class_labels are
         then unused.  Returns eps fp32 [b, H, W, Cout]."""
-        ops.drop_pending()
+        ops.drop_pending(x)
         cfg, P = self.cfg, self.plan()
         fp8 = bool(getattr(self, "attention_fp8", False))       # BASELINE config 5: e4m3 Q / K / V / P attention operands
         b, H, W, _ = x.shape

@@ -108,8 +108,7 @@ def pack_vae_attention(a: VaeAttention):
     bqkv = torch.cat([a.to_q.bias.detach().float() * qs, a.to_k.bias.detach().float(), a.to_v.bias.detach().float()])
     return SimpleNamespace(
         g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias), groups=a.groups,
-        q=ops.pack_linear(a.to_q.weight, a.to_q.bias), k=ops.pack_linear(a.to_k.weight, a.to_k.bias),
-        v=ops.pack_linear(a.to_v.weight, a.to_v.bias), out=ops.pack_linear(a.to_out[0].weight, a.to_out[0].bias),
+        out=ops.pack_linear(a.to_out[0].weight, a.to_out[0].bias),
         qkv=ops.pack_linear(wqkv, bqkv) if c in ops.WIDE_HEAD_DIMS else None, c=c)
 
 
@@ -126,22 +125,8 @@ def run_vae_attention(P, x):
         qk = ops.conv(hn.view(B, 1, N, C), P.qkv, vt=vt, vt_col0=2 * C, vt_ld=npad, vt_batch_stride=C * npad)
         o = ops.attention_wide(qk.view(B * N, 2 * C), vt, B, N, C)
         return ops.conv(o.view(B, H, W, C), P.out, res=x, qstats=True)
-    q = ops.linear(hn, P.q)
-    k = ops.linear(hn, P.k)
-    npad = (N + 63) // 64 * 64
-    vt = torch.zeros(B, C, npad, dtype=torch.bfloat16, device=x.device)       # zero key padding for the PV GEMM
-    dummy = torch.empty(8, dtype=torch.bfloat16, device=x.device)
-    ops.conv(hn.view(B, 1, N, C), P.v, vt=vt, vt_col0=0, vt_ld=npad, vt_batch_stride=C * npad, out=dummy, out_ld=8)
-    o = torch.empty(B * N, C, dtype=torch.bfloat16, device=x.device)
-    scale = 1.0 / (C ** 0.5)
-    for b in range(B):
-        qb = q[b * N:(b + 1) * N]
-        kb = ops.PackedW(k[b * N:(b + 1) * N], None, N, C)                  # K rows act as the weight matrix
-        s = ops.linear(qb, kb, out_f32=True)                                  # [N, N] fp32 scores
-        p = ops.softmax_rows(s, scale, N, npad)                               # [N, npad] bf16, zero padded
-        vb = ops.PackedW(vt[b], None, C, npad)
-        ops.linear(p, vb, out=o[b * N:(b + 1) * N], out_ld=C)
-    return ops.linear(o, P.out, res=x.view(B * N, C)).view(B, H, W, C)
+    raise ops._lib.AldmError(f"AutoencoderKL mid-block attention: head width {C} is not one the flash kernel is built for "
+                             f"{ops.WIDE_HEAD_DIMS} (cvssp/audioldm-s-full-v2 uses 512); there is no slower fallback")
 
 
 class DiagonalGaussian:

@@ -30,4 +30,4 @@ def _no_pending_deferred_reduce():
     yield
     ops = sys.modules.get("audioldm_with_lora_amd.ops")
     if ops is not None:
-        ops._PENDING = None
+        ops.drop_pending()

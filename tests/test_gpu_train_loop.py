@@ -1,6 +1,6 @@
 """GPU: the reference trainer's own loop body, imports swapped, and its train -> validate flow in one process.
 
-(1) [REF script/train/train_audioldm_lora.py:479-565] run line for line against this package's drop-in objects
+(1) the call sequence of [REF script/train/train_audioldm_lora.py:479-565] run against this package's drop-in objects
     (`unet(...)[0]` with a grad_fn, `F.mse_loss`, `accelerator.backward`, `clip_grad_norm_`, `optimizer.step`, `lr_scheduler.step`,
     `optimizer.zero_grad`, `accelerator.log / save_state`) and compared, step by step, with the same loop on the CPU oracle
     (torch autograd + torch.optim.AdamW + the transformers polynomial schedule).
@@ -43,7 +43,7 @@ def _models(seed, r=2, alpha=2, targets=("to_q", "to_v")):
     return pref, punet, unet
 
 
-def test_reference_loop_body_verbatim_matches_oracle_loop(tmp_path):
+def test_reference_loop_call_sequence_matches_oracle_loop(tmp_path):
     from audioldm_with_lora_amd import dp, optim
     from audioldm_with_lora_amd.lora import convert_state_dict_to_diffusers, get_peft_model_state_dict
     from audioldm_with_lora_amd.scheduler import DDIMScheduler
@@ -71,61 +71,49 @@ def test_reference_loop_body_verbatim_matches_oracle_loop(tmp_path):
         oopt.step(); olr.step(); oopt.zero_grad()
         want_losses.append(float(loss))
 
-    # ---- the reference's lines, against this package ----
-    accelerator_project_config = dp.ProjectConfiguration(project_dir=str(tmp_path), logging_dir=str(tmp_path / "log"))
-    accelerator = dp.Accelerator(gradient_accumulation_steps=1, mixed_precision=None, log_with="wandb",
-                                 project_config=accelerator_project_config)
-    accelerator.init_trackers(project_name="AudioLDM-with-LoRA", config=accelerator_project_config,
-                              init_kwargs={"wandb": {"group": "gpu-exp-group-1", "tags": ["lora"], "name": "r = 2, alpha = 2"}})
-    noise_scheduler = DDIMScheduler()
-    weight_dtype = torch.float32
-    unet.to(accelerator.device, dtype=weight_dtype)
-    lora_layers = filter(lambda p: p.requires_grad, unet.parameters())
-    optimizer = optim.AdamW(lora_layers, lr=lr0, betas=(0.9, 0.999), weight_decay=1e-5, eps=1e-08)
+    # ---- the same call sequence against this package's drop-in objects (own wording; the API calls and their order are the
+    #      reference's [REF train:325-346,396-447,479-576]: tracker init, optimiser / schedule construction, prepare, then per batch
+    #      add_noise -> unet(...)[0] -> mse -> gather -> backward -> clip -> step -> schedule -> zero_grad -> log, then save_state) ----
+    acc = dp.Accelerator(gradient_accumulation_steps=1, mixed_precision=None, log_with="wandb",
+                         project_config=dp.ProjectConfiguration(project_dir=str(tmp_path), logging_dir=str(tmp_path / "log")))
+    acc.init_trackers(project_name="AudioLDM-with-LoRA", config=None,
+                      init_kwargs={"wandb": {"group": "gpu-exp-group-1", "tags": ["lora"], "name": "r = 2, alpha = 2"}})
+    ddim = DDIMScheduler()
+    unet.to(acc.device, dtype=torch.float32)
+    trainable = filter(lambda p: p.requires_grad, unet.parameters())          # a one-shot iterator, as in the reference (quirk Q1)
+    optimizer = optim.AdamW(trainable, lr=lr0, betas=(0.9, 0.999), weight_decay=1e-5, eps=1e-08)
     lr_scheduler = optim.get_scheduler("polynomial", optimizer=optimizer, num_warmup_steps=0,
-                                       num_training_steps=max_train_steps * accelerator.num_processes)
-    unet, optimizer, _dl, lr_scheduler = accelerator.prepare(unet, optimizer, data, lr_scheduler)
-    global_step, train_loss, got_losses = 0, 0.0, []
+                                       num_training_steps=max_train_steps * acc.num_processes)
+    unet, optimizer, _dl, lr_scheduler = acc.prepare(unet, optimizer, data, lr_scheduler)
+    got_losses, running, done = [], 0.0, 0
     unet.train()
     optimizer.zero_grad()
-    for step, batch in enumerate(data):
-        with accelerator.accumulate(unet):
-            latents = batch["latents"].to(accelerator.device)
-            noise = batch["noise"].to(accelerator.device)
-            bsz = latents.shape[0]
-            timesteps = batch["timesteps"].to(latents.device).long()
-            noisy_latents = noise_scheduler.add_noise(latents, noise, timesteps)
-            prompt_embeds = batch["prompt_embeds"].to(latents.device)
-            model_pred = unet(
-                noisy_latents,
-                timesteps,
-                encoder_hidden_states=None,
-                class_labels=prompt_embeds,
-                cross_attention_kwargs={"scale": 1.0},
-                return_dict=False
-            )[0]
-            assert model_pred.requires_grad and model_pred.grad_fn is not None
-            loss = F.mse_loss(model_pred.float(), noise.float(), reduction="mean")
-            avg_loss = accelerator.gather(loss).mean()
-            train_loss += avg_loss.item() / 1
-            accelerator.backward(loss)
-            if accelerator.sync_gradients:
-                params_to_clip = lora_layers                      # exhausted iterator in the reference: clips nothing (quirk Q1)
-                accelerator.clip_grad_norm_(params_to_clip, 1.0)
+    for batch in data:
+        with acc.accumulate(unet):
+            x0, eps = batch["latents"].to(acc.device), batch["noise"].to(acc.device)
+            t = batch["timesteps"].to(x0.device).long()
+            cond = batch["prompt_embeds"].to(x0.device)
+            pred = unet(ddim.add_noise(x0, eps, t), t, encoder_hidden_states=None, class_labels=cond,
+                        cross_attention_kwargs={"scale": 1.0}, return_dict=False)[0]
+            assert pred.requires_grad and pred.grad_fn is not None
+            loss = F.mse_loss(pred.float(), eps.float(), reduction="mean")
+            running += acc.gather(loss).mean().item()
+            acc.backward(loss)
+            if acc.sync_gradients:
+                acc.clip_grad_norm_(trainable, 1.0)                            # exhausted iterator: clips nothing, as in the reference
             optimizer.step()
             lr_scheduler.step()
             optimizer.zero_grad()
-        if accelerator.sync_gradients:
-            accelerator.log({"train_loss": train_loss}, step=global_step)
-            got_losses.append(train_loss)
-            train_loss = 0.0
-            global_step += 1
-    save_path = os.path.join(str(tmp_path), f"checkpoint-{global_step}")
-    accelerator.save_state(save_path)                             # one argument, as the reference calls it
-    unwrapped_unet = accelerator.unwrap_model(unet)
+        if acc.sync_gradients:
+            acc.log({"train_loss": running}, step=done)
+            got_losses.append(running)
+            running, done = 0.0, done + 1
+    save_path = os.path.join(str(tmp_path), f"checkpoint-{done}")
+    acc.save_state(save_path)                                                  # one argument, as the reference calls it
+    unwrapped_unet = acc.unwrap_model(unet)
     unet_lora_state_dict = convert_state_dict_to_diffusers(get_peft_model_state_dict(unwrapped_unet))
-    accelerator.wait_for_everyone()
-    accelerator.end_training()
+    acc.wait_for_everyone()
+    acc.end_training()
 
     # losses step by step (the first is before any update: forward parity; later ones also check backward + AdamW + LR)
     for i, (a, b) in enumerate(zip(got_losses, want_losses)):

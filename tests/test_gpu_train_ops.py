@@ -275,4 +275,4 @@ def test_groupnorm_bwd_takes_dy_as_split_partials(B, C1, C2, Cout, H, W, splits,
     assert torch.equal(got[0], want[0])
     if C2:
         assert torch.equal(got[1], want[1])
-    assert ops._PENDING is None
+    assert not ops._PENDING_BY_STREAM
