@@ -20,6 +20,7 @@ UNET = dict(
     norm_eps=1e-5,
     flip_sin_to_cos=True,
     freq_shift=0,
+    sample_size=128,                  # SURVEY.md A.1; only the pipeline's default clip length reads it
 )
 
 VAE = dict(
