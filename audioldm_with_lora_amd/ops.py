@@ -191,7 +191,7 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     otherwise the grid runs in two rounds (128x64 tile, 500 workgroups: ring 4 = 98 KiB/WG -> 38.9 us, ring 3 -> 23.9 us);
     then depth -- few workgroups (low-resolution levels) have nothing else to hide the weight stream's latency behind, so
     they take the deepest ring that fits; big grids gain nothing past 2-3."""
-    if tile == 6:
+    if tile in (6, 9):
         return 2
     stage = (bm + bn + rp) * 128
     extra = (bn * 128 if rp else 0) + 2 * bm * 4
@@ -201,7 +201,7 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     return max(2, min(want, fit))
 
 
-TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128)}
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128)}
 HALO_ROWS = {7: 192, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip)
 
 
@@ -264,7 +264,8 @@ class Tuner:
         lib = _lib.load()
         default = heuristic_cfg(M, pw, ktiles, can_split, fast_path, has_vt, forced_splits)
         cands = []
-        for t in [2, 3, 1, 4] + ([6] if (fast_path and not has_vt and ktiles >= 8) else []):
+        for t in [2, 3, 1, 4] + ([6] if (fast_path and not has_vt and ktiles >= 8) else []) + (
+                [9] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M >= 32768 and pw.N % 128 == 0) else []):
             bm, bn = TILE_DIMS[t]
             if has_vt and a.vt_col0 % bn:
                 continue
@@ -274,7 +275,7 @@ class Tuner:
                 sp_list += [sp for sp in (2, 3, 4, 6, 8, 12, 16)
                             if sp <= ktiles // 2 and base * sp <= 2560 and sp * M * pw.N * 4 <= (1 << 28)]
             for sp in sp_list:
-                for rg in ((2, 3) if t == 6 else (2, 3, 4)):
+                for rg in ((2, 3) if t in (6, 9) else (2, 3, 4)):
                     cands.append((t, rg, sp))
         if forced_splits in (None, 1):
             cands += [(t, rg, 1) for t in halo for rg in (2, 3, 4)]
@@ -334,7 +335,7 @@ def save_tuned(path=TUNED_PATH):
                    "igemm": {k: list(v) for k, v in sorted(TUNED.items())}}, f, indent=0)
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event, site) per C-ABI call.
 # Events are recorded on the stream the kernel is launched on.  SITE tags the launches of one fused-LoRA attention module

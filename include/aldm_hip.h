@@ -123,7 +123,8 @@ enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE
        ALDM_TILE_32x64 = 5, ALDM_TILE_128x128_W8 = 6 /* 8-wave workgroup */,
        /* 3x3 / stride-1 / pad-1 convs only: the workgroup keeps the input halo of BM/OW image rows in LDS and reads the
           nine taps from it (csrc/igemm_halo.hip); needs Cin % 64 == 0, BM % OW == 0, no split-K / LoRA / V^T */
-       ALDM_TILE_HALO_128x128 = 7, ALDM_TILE_HALO_64x128 = 8 };
+       ALDM_TILE_HALO_128x128 = 7, ALDM_TILE_HALO_64x128 = 8,
+       ALDM_TILE_256x128_W8 = 9 /* 8-wave workgroup, 64x64 per wave: big-M plain convolutions (VAE, vocoder) */ };
 
 int aldm_igemm(const aldm_igemm_t* p, void* stream);
 size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p);

@@ -46,7 +46,7 @@ def ops():
 @pytest.mark.parametrize("B,Cin,Cout,H,W,stride,tile", [
     (2, 64, 128, 25, 16, 1, 0), (1, 128, 64, 9, 4, 1, 0), (2, 8, 128, 31, 16, 1, 0), (2, 192, 256, 16, 8, 2, 0),
     (8, 128, 128, 50, 16, 1, 1), (2, 128, 128, 13, 7, 1, 3), (2, 128, 128, 13, 7, 1, 4), (1, 640, 320, 32, 2, 1, 2),
-    (1, 128, 8, 20, 16, 1, 0),
+    (1, 128, 8, 20, 16, 1, 0), (4, 128, 256, 70, 16, 1, 9), (2, 64, 128, 129, 8, 1, 9),
 ])
 def test_conv3x3(ops, B, Cin, Cout, H, W, stride, tile):
     g = torch.Generator().manual_seed(0)
