@@ -70,6 +70,7 @@ class PgemmArgs(C.Structure):
         ("mi", C.c_int), ("nt", C.c_int), ("tiles_per_range", C.c_int),
         ("max_ranges", C.c_int),
         ("waves", C.c_int),
+        ("lora_t_out", C.c_void_p),
     ]
 
 

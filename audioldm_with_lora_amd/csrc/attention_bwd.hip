@@ -9,11 +9,14 @@
 //                  dV^T += dO^T P and dK^T += Q^T dS with Q^T / dO^T token-major from LDS.  No atomics anywhere:
 //                  every output element has exactly one owner.
 // Token-major copies (Q^T, K^T, dO^T as [B][C][Npad]) come from aldm_transpose_tokens.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int TS = 64;   // tokens per staged tile
+constexpr int ATTN_BWD_NW8_MIN_N = 768;   // 8-wave workgroups from this many tokens on (N = 1024: 93.5 -> 90.7 us per backward; N = 256: 33.6 -> 38.7, stays at 4)
 constexpr int VS = 136;  // token-major LDS row stride (64 tokens * 2 B + 8 B pad)
 
 template <int DP>
@@ -380,6 +383,9 @@ template <int DP>
 int launch_bwd_d(const void* q, const void* k, const void* v, int ld, const void* qT, const void* kT, const void* dOT, int ldt,
                  long long qt_bs, long long kt_bs, long long dot_bs, const void* dO, const void* O, int ldo, const float* lse,
                  float* delta, int B, int N, int H, int D, float scale, void* dq, void* dk, void* dv, int ldg, hipStream_t st) {
+  static const int nw_override = []() { const char* e = getenv("ALDM_ATTN_BWD_NW"); return e ? atoi(e) : 0; }();   // tuning aid (tools/bench_attn_bwd.py)
+  if (nw_override == 8 || (nw_override == 0 && N >= ATTN_BWD_NW8_MIN_N)) return launch_bwd<DP, 8>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
+  if (nw_override == 2) return launch_bwd<DP, 2>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
   if (N >= 192) return launch_bwd<DP, 4>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
   if (N >= 64) return launch_bwd<DP, 2>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);
   return launch_bwd<DP, 1>(q, k, v, ld, qT, kT, dOT, ldt, qt_bs, kt_bs, dot_bs, dO, O, ldo, lse, delta, B, N, H, D, scale, dq, dk, dv, ldg, st);

@@ -39,7 +39,7 @@ using aldm_igemm_detail::wait_vmcnt;
 struct PgArgs {
   const bf16* lora_a; const bf16* lora_b;
   const float* bias; const float* ln_s; const float* ln_sa; const float* ln_ca; const float* ln_parts;
-  const bf16* res; bf16* out; bf16* vt; float* rowstat;
+  const bf16* res; bf16* out; bf16* vt; float* rowstat; bf16* lora_t;
   int Rp, ln_np, out_ld;
   int vt_col0, vt_ld, OHW, vt_vec;        // vt_vec: tokens per V^T store (8, 4 or 1)
   long long vt_bs;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
     typedef const PgArgs __attribute__((address_space(4))) * pa_ptr_t;
     pa_ptr_t ps = (pa_ptr_t)(ka + PG_STRUCT_OFFSET);
     p.lora_a = ps->lora_a; p.lora_b = ps->lora_b; p.bias = ps->bias; p.ln_s = ps->ln_s; p.ln_sa = ps->ln_sa; p.ln_ca = ps->ln_ca;
-    p.ln_parts = ps->ln_parts; p.res = ps->res; p.out = ps->out; p.vt = ps->vt; p.rowstat = ps->rowstat;
+    p.ln_parts = ps->ln_parts; p.res = ps->res; p.out = ps->out; p.vt = ps->vt; p.rowstat = ps->rowstat; p.lora_t = ps->lora_t;
     p.Rp = ps->Rp; p.ln_np = ps->ln_np; p.out_ld = ps->out_ld; p.vt_col0 = ps->vt_col0; p.vt_ld = ps->vt_ld; p.OHW = ps->OHW;
     p.vt_vec = ps->vt_vec; p.vt_bs = ps->vt_bs; p.fd_ohw.mul = ps->fd_ohw.mul; p.fd_ohw.shift = ps->fd_ohw.shift;
     p.ln_eps = ps->ln_eps; p.diag = ps->diag;
@@ -291,6 +291,11 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
             if constexpr (LN) v = v - mean[i] * sa[rt][e] + ca[rt][e] * irs;
             tf[i][4 * rt + e] = (bf16)v;
           }
+          // training: T = x A^T is an operand of the LoRA gradient products (dB = s dY^T T): the first column range of every row
+          // block stores its copy, [M][Rp] bf16, ranks 16 rt + 4 q .. + 3 of row mrow[i]
+          if (p.lora_t && nr == 0 && mrow[i] < M)
+            *reinterpret_cast<bf16x4*>(p.lora_t + (long long)mrow[i] * p.Rp + 16 * rt + 4 * q) =
+                bf16x4{tf[i][4 * rt], tf[i][4 * rt + 1], tf[i][4 * rt + 2], tf[i][4 * rt + 3]};
         }
       }
     }
@@ -702,6 +707,7 @@ extern "C" int aldm_pgemm(const aldm_pgemm_t* g0, void* stream) {
     rt = g->ranks_used <= 16 ? 1 : 2;
     ALDM_CHECK_ARG(!g->ln_s || (g->ln_sa && g->ln_ca), "pgemm: folded LayerNorm with LoRA needs ln_sa / ln_ca");
   }
+  ALDM_CHECK_ARG(!g->lora_t_out || g->Rp, "pgemm: lora_t_out without an adapter");
   ALDM_CHECK_ARG(!g->ln_s || (g->ln_parts && g->ln_nparts > 0 && g->ln_nparts <= 16), "pgemm: the folded LayerNorm takes its statistics from ln_parts (1 .. 16 pairs per row)");
   ALDM_CHECK_ARG(!(g->geglu && (g->vt || g->res || g->rowstat_out || g->Rp)), "pgemm: GEGLU launches take no V^T / residual / statistics / LoRA");
   ALDM_CHECK_ARG(!g->geglu || nt == 64, "pgemm: GEGLU needs nt = 64");
@@ -717,7 +723,7 @@ extern "C" int aldm_pgemm(const aldm_pgemm_t* g0, void* stream) {
   PgArgs& a = h.a;
   a.lora_a = (const bf16*)g->lora_a; a.lora_b = (const bf16*)g->lora_b;
   a.bias = g->bias; a.ln_s = g->ln_s; a.ln_sa = g->ln_sa; a.ln_ca = g->ln_ca; a.ln_parts = g->ln_parts;
-  a.res = (const bf16*)g->res; a.out = (bf16*)g->out; a.vt = (bf16*)g->vt; a.rowstat = g->rowstat_out;
+  a.res = (const bf16*)g->res; a.out = (bf16*)g->out; a.vt = (bf16*)g->vt; a.rowstat = g->rowstat_out; a.lora_t = (bf16*)g->lora_t_out;
   a.Rp = g->Rp; a.ln_np = g->ln_nparts; a.out_ld = g->out_ld;
   a.vt_col0 = g->vt ? g->vt_col0 : 0x7fffffff; a.vt_ld = g->vt_ld; a.OHW = g->OHW > 0 ? g->OHW : g->M; a.vt_bs = g->vt_batch_stride;
   a.vt_vec = 1;

@@ -17,21 +17,24 @@ namespace {
 
 constexpr int GN_THREADS = 512;
 
+template <int NT = GN_THREADS>
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red, int tid) {
   a = wave_sum(a);
   b = wave_sum(b);
   __syncthreads();
-  if ((tid & 63) == 0) { red[tid >> 6] = a; red[8 + (tid >> 6)] = b; }
+  if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; }
   __syncthreads();
   float ta = 0.f, tb = 0.f;
 #pragma unroll
-  for (int i = 0; i < GN_THREADS / 64; ++i) { ta += red[i]; tb += red[8 + i]; }
+  for (int i = 0; i < NT / 64; ++i) { ta += red[i]; tb += red[16 + i]; }
   a = ta; b = tb;
 }
 
-// y = act(gn(x)) ; given dy -> dx.  One workgroup per (image, group), strip in registers (<= 512*QPT quads).
-template <int QPT>
-__global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x2,
+// y = act(gn(x)) ; given dy -> dx.  One workgroup per (image, group), strip in registers (<= NT*QPT quads).  The long strips
+// (4096 pixels) run with NT = 1024 threads: half the registers per thread, 16 waves per workgroup to hide the strided 8-byte loads
+// (a strip is Cg*2 bytes out of every pixel row) -- measured 121 -> 75 us at 4096 x 384 (34 -> 31, 25 -> 23 us for the two shorter long-strip shapes).
+template <int QPT, int NT = GN_THREADS>
+__global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x2,
                                                                    const bf16* __restrict__ dy, int HW, int C1, int C2,
                                                                    int groups, float eps, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, int act,
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
                                                                    const float* __restrict__ dy_ws, int dy_splits, long long dy_sstride) {
   // dy_ws: dY still as the split-K partial tiles [dy_splits][B*HW][C] (fp32) of the dX convolution that produced it
   // (aldm_igemm defer_reduce): summed here in split order and rounded to bf16, exactly what igemm_reduce_kernel would store
-  __shared__ float red[16];
+  __shared__ float red[32];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
   const int nb = gridDim.x / groups;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
   float s = 0.f, dummy = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
-    const int q = tid + i * GN_THREADS;
+    const int q = tid + i * NT;
     bf16x4 t = {0, 0, 0, 0}, u = {0, 0, 0, 0};
     if (q < nquads) {
       const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
@@ -83,24 +86,24 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
     s += (float)t[0] + (float)t[1] + (float)t[2] + (float)t[3];
   }
   const float n = (float)nquads * 4.f;
-  block_sum2(s, dummy, red, tid);
+  block_sum2<NT>(s, dummy, red, tid);
   const float mean = s / n;
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i)
-    if (tid + i * GN_THREADS < nquads) {
+    if (tid + i * NT < nquads) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { const float e = (float)v[i][k] - mean; ss += e * e; }
     }
   dummy = 0.f;
-  block_sum2(ss, dummy, red, tid);
+  block_sum2<NT>(ss, dummy, red, tid);
   const float rstd = rsqrtf(ss / n + eps);
 
   // gdz = dz * gamma kept in fp32 registers would double the footprint: recompute it in the second sweep
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
-    const int q = tid + i * GN_THREADS;
+    const int q = tid + i * NT;
     if (q < nquads) {
       const int j = q - aldm_div(q, dqpp) * qpp;
       const int c = c0 + 4 * j;
@@ -119,12 +122,12 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const bf16* _
       }
     }
   }
-  block_sum2(s1, s2, red, tid);
+  block_sum2<NT>(s1, s2, red, tid);
   s1 /= n;
   s2 /= n;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
-    const int q = tid + i * GN_THREADS;
+    const int q = tid + i * NT;
     if (q < nquads) {
       const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
@@ -567,10 +570,16 @@ static int groupnorm_bwd_impl(const void* x, const void* x2, const void* dy, con
                      (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
                      (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc, dq, dy_ws, dy_splits,           \
                      (long long)B * HW * C)
+#define ALDM_GNB_WIDE(QPT)                                                                                             \
+  hipLaunchKernelGGL((groupnorm_bwd_kernel<QPT, 1024>), dim3(B * groups), dim3(1024), 0, (hipStream_t)stream,          \
+                     (const bf16*)x, (const bf16*)x2, (const bf16*)dy, HW, C1, C2, groups, eps, gamma, beta, act,      \
+                     (bf16*)dx, (bf16*)dx2, (const bf16*)dx_acc, (const bf16*)dx2_acc, dq, dy_ws, dy_splits,           \
+                     (long long)B * HW * C)
   if (nquads <= 4 * GN_THREADS) ALDM_GNB(4);
-  else if (nquads <= 8 * GN_THREADS) ALDM_GNB(8);
-  else if (nquads <= 16 * GN_THREADS) ALDM_GNB(16);
-  else ALDM_GNB(32);
+  else if (nquads <= 4 * 1024) ALDM_GNB_WIDE(4);
+  else if (nquads <= 8 * 1024) ALDM_GNB_WIDE(8);
+  else ALDM_GNB_WIDE(16);
+#undef ALDM_GNB_WIDE
 #undef ALDM_GNB
   return aldm_launch_status("groupnorm_bwd");
 }

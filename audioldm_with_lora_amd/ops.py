@@ -494,7 +494,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             and not in_dilate and in_act == ACT_NONE and x2 is None and x3 is None and pw.Kpad == C1 and C1 in PGEMM_K
             and pw.N % 64 == 0 and out.dtype == torch.bfloat16 and out_pix_stride == 1 and out_pix_offset == 0
             and out_batch_stride == OH * OW * out_ld and out_ld % 8 == 0 and rowbias is None and out_act == ACT_NONE
-            and post_act == ACT_NONE and res2 is None and out2 is None and alpha == 1.0 and lora_t_out is None
+            and post_act == ACT_NONE and res2 is None and out2 is None and alpha == 1.0 and (lora_t_out is None or pw.Rp)
             and splits in (None, 1) and gn is None and not vt_dual
             and not (qstats and OH * OW >= QSTATS_MIN_HW)
             and (not pw.Rp or getattr(pw, "ranks_used", 99) <= 32)
@@ -503,7 +503,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             and not (vt is not None and (res is not None or rowstats or vt_col0 % 32 or vt_col0 <= 0))
             and (res is None or (res.is_contiguous() and res.numel() == B * OH * OW * out_ld))
             and PGEMM_CFG.get(_pgemm_key(B * OH * OW, pw, C1, res, vt)) != PGEMM_USE_IGEMM):
-        return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts)
+        return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts, lora_t_out)
     a = IgemmArgs()
     if x3 is not None:
         for t in (x3, x4):
@@ -689,7 +689,7 @@ def _pgemm_key(M, pw, K, res, vt):
     return (M, pw.N, K, kind)
 
 
-def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowstats, ln_parts):
+def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowstats, ln_parts, lora_t_out=None):
     """conv()'s 1x1 / short-K case on aldm_pgemm: same operands, same results (to rounding), a kernel built for it."""
     lib = _lib.load()
     a = _lib.PgemmArgs()
@@ -705,6 +705,9 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
         raise _lib.AldmError("conv: ln_parts without a LayerNorm-folded weight pack (pack_linear_ln)")
     if pw.Rp:
         a.lora_a, a.lora_b, a.Rp, a.ranks_used = pw.lora_a.data_ptr(), pw.lora_b.data_ptr(), pw.Rp, pw.ranks_used
+        if lora_t_out is not None:
+            assert lora_t_out.dtype == torch.bfloat16 and lora_t_out.is_contiguous() and tuple(lora_t_out.shape) == (M, pw.Rp)
+            a.lora_t_out = lora_t_out.data_ptr()
     a.geglu = 1 if pw.geglu else 0
     a.res = res.data_ptr() if res is not None else None
     a.out, a.out_ld = out.data_ptr(), out_ld

@@ -193,6 +193,7 @@ class LoraSite:
         self.bwd.lora_a = torch.zeros(self.Rp, npad, dtype=torch.bfloat16, device=dev)
         self.bwd.lora_b = torch.zeros(self.K, self.Rp, dtype=torch.bfloat16, device=dev)
         self.bwd.Rp = self.Rp
+        self.fwd.ranks_used = self.bwd.ranks_used = rtot     # (<= 32: the K = 256 / 384 / 640 launches may run on aldm_pgemm)
         self.jobs = []
         rows_db = [(0, 0, 0, 0, 0.0)] * self.Rp
         rows_da = [(0, 0, 0, 0, 0.0)] * self.Rp

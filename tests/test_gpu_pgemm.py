@@ -189,6 +189,26 @@ def test_geglu_layernorm_folded(ops, labels, M, C, nparts):
     assert all(l[0].startswith("pgemm_") for l in labels), [l[0] for l in labels]
 
 
+def test_lora_t_copy_for_the_trainer(ops, labels):
+    """lora_t_out: the bf16 T = x A^T the LoRA gradient products consume, identical to what aldm_igemm stores"""
+    g = torch.Generator().manual_seed(8)
+    M, K, N, r = 1000, 256, 256, 8
+    x = dv(torch.randn(M, K, generator=g))
+    pw = ops.pack_linear((torch.randn(N, K, generator=g) / 16).to(DEV), torch.randn(N, generator=g).to(DEV))
+    A = bf(torch.randn(r, K, generator=g) / r)
+    ops.attach_lora(pw, [(0, N, A.to(DEV), (torch.randn(N, r, generator=g) * 0.05).to(DEV), 1.0)])
+    res = dv(torch.randn(M, N, generator=g))
+    t_new = torch.zeros(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
+    t_old = torch.zeros(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
+    y_new = ops.linear(x, pw, res=res, lora_t_out=t_new)
+    y_old = ops.linear(x, pw, res=res, lora_t_out=t_old, tile=2)                # the convolution kernel
+    close(t_new[:, :r], x.float().cpu() @ A.t())
+    assert not t_new[:, r:].any()
+    assert float((t_new.float() - t_old.float()).abs().max()) <= 2 ** -6 * float(t_old.float().abs().max())
+    assert float((y_new.float() - y_old.float()).abs().max()) <= 2 ** -6 * float(y_old.float().abs().max())
+    assert labels[0][0].startswith("pgemm_") and labels[1][0].startswith("igemm_")
+
+
 def test_cold_launches_are_deterministic(ops):
     """Race screen.  Every operand of the kernel reaches LDS asynchronously (LDS-DMA ring, column vectors, LoRA-B rows) behind
     counted waits and barriers; a read that beats its data shows up only when the LDS still holds something else.  So: two different

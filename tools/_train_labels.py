@@ -1,0 +1,25 @@
+import collections, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from audioldm_with_lora_amd import ops
+from audioldm_with_lora_amd.training import LoraTrainer
+from audioldm_with_lora_amd.scheduler import DDIMScheduler
+unet, _ = bench.build_unet(8)
+tr = LoraTrainer(unet, DDIMScheduler(), lr=1e-5, weight_decay=1e-5, max_train_steps=97000, use_graph=False)
+g = torch.Generator().manual_seed(0)
+lat, noise = torch.randn(8, 8, 256, 16, generator=g).cuda(), torch.randn(8, 8, 256, 16, generator=g).cuda()
+t = torch.randint(0, 1000, (8,), generator=g).cuda()
+emb = torch.nn.functional.normalize(torch.randn(8, 512, generator=g), dim=-1).cuda()
+tr.step(lat, noise, t, emb)
+ops.PROFILE = []
+ops.sleep_us(50000)
+tr.step(lat, noise, t, emb)
+torch.cuda.synchronize()
+rows, ops.PROFILE = ops.PROFILE, None
+agg = collections.defaultdict(lambda: [0, 0.0])
+for label, fl, nb, s, e, site in rows:
+    agg[label][0] += 1
+    agg[label][1] += s.elapsed_time(e) * 1e3
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{v[1]:8.1f} us {v[0]:3d}x {v[1] / v[0]:6.1f}  {k}")
+print("labelled launches:", len(rows))

@@ -51,6 +51,14 @@ def main():
     eng.set_latents(lat)
     tune(eng.step, tuner, args.passes)
     print(f"[autotune] inference: {len(tuner.cands)} GEMMs, {time.time() - t0:.1f} s", flush=True)
+    # the reference's own inference call: one prompt (UNet batch 2), 50 steps [REF script/inference/generate_audio.py:47-52]
+    eng1 = DenoiseEngine(unet, DDIMScheduler(), 1, 250, 16, 50, 5.0, use_graph=False)
+    lat1, pe1, ne1 = bench.synth_inputs(1, 250, 16)
+    eng1.set_condition(pe1, ne1)
+    eng1.set_latents(lat1)
+    tune(eng1.step, tuner, args.passes)
+    print(f"[autotune] + inference at batch 1: {len(tuner.cands)} GEMMs, {time.time() - t0:.1f} s", flush=True)
+    del eng1
 
     from audioldm_with_lora_amd.vae import AutoencoderKL
     from audioldm_with_lora_amd.vocoder import SpeechT5HifiGan
@@ -59,7 +67,17 @@ def main():
     z = torch.randn(4, 8, 250, 16, device="cuda")
     tune(lambda: voc(vae.decode(z / vae.config.scaling_factor).sample.squeeze(1)), tuner, args.passes)
     print(f"[autotune] + VAE decode / vocoder: {len(tuner.cands)} GEMMs, {time.time() - t0:.1f} s", flush=True)
-    del eng, unet, vae, voc
+    # the training loop body's input side [REF train:495-524]: VAE encode of 8 log-mels, CLAP text tower on captions of <= 64 tokens
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.script.train import synthetic_batch
+    clap = ClapTextModelWithProjection().cuda()
+    b = synthetic_batch(8, torch.Generator().manual_seed(21), vocab=clap.cfg["vocab_size"])
+    mel = b["log_mel_spec"].cuda()
+    ids = b["input_ids"].squeeze(1)[:, :64].cuda().contiguous()
+    kv = clap._lengths(b["input_ids"].squeeze(1), b["attention_mask"].squeeze(1)).cuda()
+    tune(lambda: (vae.encode(mel), clap.forward_device(ids, kv)), tuner, args.passes)
+    print(f"[autotune] + VAE encode / CLAP tower: {len(tuner.cands)} GEMMs, {time.time() - t0:.1f} s", flush=True)
+    del eng, unet, vae, voc, clap
     torch.cuda.empty_cache()
 
     from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model

@@ -30,6 +30,15 @@ def make_case(kind, M, N, K, B, nbuf=3):
     if kind == "proj_in":
         pw = ops.pack_linear(w, b)
         return "", lambda i: ops.linear(xs[i], pw, rowstats=True)
+    if kind == "plain":
+        pw = ops.pack_linear(w, b)
+        return "", lambda i: ops.linear(xs[i], pw)
+    if kind == "out_t":                                      # the trainer's to_out.0: rank 8, T copy, residual
+        pw = ops.pack_linear(w, b)
+        ops.attach_lora(pw, [(0, N, (torch.randn(8, K, generator=g) / 8).to(DEV), (torch.randn(N, 8, generator=g) * 0.05).to(DEV), 1.0)])
+        res = [torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) for _ in range(nbuf)]
+        T = torch.empty(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
+        return f"rl{pw.Rp}", lambda i: ops.linear(xs[i], pw, res=res[i], lora_t_out=T)
     if kind == "out":
         pw = ops.pack_linear(w, b)
         ops.attach_lora(pw, [lora(0, N)])
@@ -52,13 +61,13 @@ def make_case(kind, M, N, K, B, nbuf=3):
 def configs(kind, M, N, K):
     out = []
     for nw in (4, 8):
-        for mi in ((1, 2) if ((K <= 384 or kind in ("proj_in", "ff1")) and nw == 4) else (1,)):
+        for mi in ((1, 2) if ((K <= 384 or kind in ("proj_in", "ff1", "plain")) and nw == 4) else (1,)):
             for nt in ((64,) if kind == "ff1" else (32, 64)):
                 if kind == "qkv" and (2 * N // 3) % nt:
                     continue
                 nti = N // nt
-                res = kind == "out"
-                rp = 32 if kind in ("out", "qkv") else 0
+                res = kind in ("out", "out_t")
+                rp = 32 if kind in ("out", "qkv", "out_t") else 0
                 bm = 16 * mi * nw
                 stage = nt * K * 2 + (bm * nt * 2 if res else 0)
                 for t in range(1, nti + 1):
@@ -98,14 +107,21 @@ def main():
     ap.add_argument("--reps", type=int, default=24)
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--train", action="store_true", help="also the taped training step's shapes (batch 8 x 256x16 latents)")
     a = ap.parse_args()
     table = {}
     nbuf = 3
-    for B in a.batch:
-        levels = [(256, 1000), (384, 252), (640, 64)]
-        for C, n in levels:
+    path = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "pgemm_gfx950.json")
+    if os.path.exists(path):                                 # keep what earlier runs measured
+        table.update(json.load(open(path))["pgemm"])
+    jobs = [(B, C, n, kinds) for B in a.batch for C, n, kinds in
+            ((256, 1000, None), (384, 252, None), (640, 64, None))]
+    if a.train:                                              # proj_in / its dX / ff2's dX (plain), to_out.0 forward (LoRA + residual + T copy)
+        jobs += [(8, C, n, (("plain", C), ("plain", 4 * C), ("out_t", C))) for C, n in ((256, 1024), (384, 256), (640, 64))]
+    for B, C, n, kinds in jobs:
+        if True:
             M = B * n
-            for kind, N in (("proj_in", C), ("qkv", 3 * C), ("out", C), ("ff1", 8 * C)):
+            for kind, N in (kinds or (("proj_in", C), ("qkv", 3 * C), ("out", C), ("ff1", 8 * C))):
                 if a.only and a.only != kind:
                     continue
                 sfx, run = make_case(kind, M, N, C, B, nbuf)
@@ -130,7 +146,6 @@ def main():
                 # (a GEMM that measures faster on the convolution kernel stays there: [0, 0, 0, 0])
                 table["|".join(map(str, key))] = list(res[0][1]) if res[0][0] <= 0.98 * old else [0, 0, 0, 0]
     if a.write:
-        path = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "pgemm_gfx950.json")
         with open(path, "w") as f:
             json.dump({"device": "MI355X gfx950", "format": "M|N|K|kind -> [mi, nt, tiles_per_range, waves]; [0, 0, 0, 0] = keep aldm_igemm", "pgemm": table}, f, indent=0, sort_keys=True)
         print("wrote", path)
