@@ -502,7 +502,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             and not (pw.geglu and (res is not None or vt is not None or pw.Rp or rowstats))
             and not (vt is not None and (res is not None or rowstats or vt_col0 % 32 or vt_col0 <= 0))
             and (res is None or (res.is_contiguous() and res.numel() == B * OH * OW * out_ld))
-            and PGEMM_CFG.get(_pgemm_key(B * OH * OW, pw, C1, res, vt)) != PGEMM_USE_IGEMM):
+            and PGEMM_CFG.get(_pgemm_key(B * OH * OW, pw, C1, res, vt, rowstats, lora_t_out is not None)) != PGEMM_USE_IGEMM):
         return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts, lora_t_out)
     a = IgemmArgs()
     if x3 is not None:
@@ -684,8 +684,9 @@ if os.path.exists(PGEMM_TUNED_PATH) and os.environ.get("ALDM_NO_TUNED") != "1":
 PGEMM_USE_IGEMM = (0, 0, 0, 0)                               # table entry: this GEMM measured faster on aldm_igemm, keep it there
 
 
-def _pgemm_key(M, pw, K, res, vt):
-    kind = ("g" if pw.geglu else "") + ("v" if vt is not None else "") + ("r" if res is not None else "") + (f"l{pw.Rp}" if pw.Rp else "")
+def _pgemm_key(M, pw, K, res, vt, rowstats=False, lora_t=False):
+    kind = (("g" if pw.geglu else "") + ("v" if vt is not None else "") + ("r" if res is not None else "") + (f"l{pw.Rp}" if pw.Rp else "")
+            + ("s" if rowstats else "") + ("t" if lora_t else ""))
     return (M, pw.N, K, kind)
 
 
@@ -713,7 +714,9 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
     a.out, a.out_ld = out.data_ptr(), out_ld
     if vt is not None:
         a.vt, a.vt_col0, a.vt_ld, a.vt_batch_stride, a.OHW = vt.data_ptr(), vt_col0, vt_ld, vt_bs, OHW
-    cfg = PGEMM_CFG.get(_pgemm_key(M, pw, K, res, vt))
+    cfg = PGEMM_CFG.get(_pgemm_key(M, pw, K, res, vt, rowstats, lora_t_out is not None))
+    if cfg is not None and rowstats and pw.N // (cfg[1] * cfg[2]) > 16:
+        cfg = None                                           # (consumers take at most 16 partial pairs per row)
     if cfg is not None:
         a.mi, a.nt, a.tiles_per_range = cfg[:3]
         a.waves = cfg[3] if len(cfg) > 3 else 4

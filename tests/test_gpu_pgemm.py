@@ -85,7 +85,7 @@ def test_plain_bias_residual_rowstats(ops, labels, M, K, N):
     pw = ops.pack_linear(w.to(DEV), b.to(DEV))
     for cfg in shapes_for(K, N, res=True):
         ops.PGEMM_CFG[(M, N, K, "")] = cfg
-        ops.PGEMM_CFG[(M, N, K, "r")] = cfg
+        ops.PGEMM_CFG[(M, N, K, "rs")] = cfg
         y = ops.linear(dv(x), pw)
         close(y, x @ w.t() + b)
         y, st = ops.linear(dv(x), pw, res=dv(res), rowstats=True)
@@ -115,7 +115,7 @@ def test_lora_residual(ops, labels, M, K, N, r):
     pwz = ops.pack_linear(w.to(DEV), b.to(DEV))
     ops.attach_lora(pwz, [(0, N, A.to(DEV), torch.zeros_like(Bm).to(DEV), 2.0)])
     for cfg in shapes_for(K, N, res=True, rp=pw.Rp):
-        for kind in ("r", f"rl{pw.Rp}"):
+        for kind in ("r", f"rl{pw.Rp}s"):
             ops.PGEMM_CFG[(M, N, K, kind)] = cfg
         y, st = ops.linear(dv(x), pw, res=dv(res), rowstats=True)
         close(y, want)

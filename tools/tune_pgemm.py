@@ -29,7 +29,7 @@ def make_case(kind, M, N, K, B, nbuf=3):
     parts[:, :, 1] = parts[:, :, 0] ** 2 + K / 4.0
     if kind == "proj_in":
         pw = ops.pack_linear(w, b)
-        return "", lambda i: ops.linear(xs[i], pw, rowstats=True)
+        return "s", lambda i: ops.linear(xs[i], pw, rowstats=True)
     if kind == "plain":
         pw = ops.pack_linear(w, b)
         return "", lambda i: ops.linear(xs[i], pw)
@@ -38,12 +38,12 @@ def make_case(kind, M, N, K, B, nbuf=3):
         ops.attach_lora(pw, [(0, N, (torch.randn(8, K, generator=g) / 8).to(DEV), (torch.randn(N, 8, generator=g) * 0.05).to(DEV), 1.0)])
         res = [torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) for _ in range(nbuf)]
         T = torch.empty(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
-        return f"rl{pw.Rp}", lambda i: ops.linear(xs[i], pw, res=res[i], lora_t_out=T)
+        return f"rl{pw.Rp}t", lambda i: ops.linear(xs[i], pw, res=res[i], lora_t_out=T)
     if kind == "out":
         pw = ops.pack_linear(w, b)
         ops.attach_lora(pw, [lora(0, N)])
         res = [torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) for _ in range(nbuf)]
-        return f"rl{pw.Rp}", lambda i: ops.linear(xs[i], pw, res=res[i], rowstats=True)
+        return f"rl{pw.Rp}s", lambda i: ops.linear(xs[i], pw, res=res[i], rowstats=True)
     if kind == "qkv":
         C = N // 3
         pw = ops.pack_linear_ln(w, None, gm, bt)
@@ -107,12 +107,13 @@ def main():
     ap.add_argument("--reps", type=int, default=24)
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--fresh", action="store_true", help="start from an empty table")
     ap.add_argument("--train", action="store_true", help="also the taped training step's shapes (batch 8 x 256x16 latents)")
     a = ap.parse_args()
     table = {}
     nbuf = 3
     path = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "pgemm_gfx950.json")
-    if os.path.exists(path):                                 # keep what earlier runs measured
+    if os.path.exists(path) and not a.fresh:                 # keep what earlier runs measured
         table.update(json.load(open(path))["pgemm"])
     jobs = [(B, C, n, kinds) for B in a.batch for C, n, kinds in
             ((256, 1000, None), (384, 252, None), (640, 64, None))]
