@@ -90,7 +90,8 @@ def test_plain_bias_residual_rowstats(ops, labels, M, K, N):
         close(y, x @ w.t() + b)
         y, st = ops.linear(dv(x), pw, res=dv(res), rowstats=True)
         close(y, x @ w.t() + b + res)
-        assert st.shape == (M, N // (cfg[1] * cfg[2]), 2)
+        nr = N // (cfg[1] * cfg[2])                           # (more than 16 partial pairs: the table entry is set aside for the plan)
+        assert st.shape == (M, nr, 2) if nr <= 16 else st.shape[1] <= 16
         s1, s2 = stats_of(y)                                  # the statistics are those of the values AS STORED
         assert torch.allclose(st[:, :, 0].sum(1).cpu(), s1, rtol=1e-4, atol=1e-2)
         assert torch.allclose(st[:, :, 1].sum(1).cpu(), s2, rtol=1e-4, atol=1e-2)
