@@ -5,7 +5,11 @@
 // V^T fragment reads reproduce with two 8-byte LDS reads).  K / V^T tiles of 64 keys are shared by the
 // workgroup's waves through padded (bank-conflict-free) LDS images, register-prefetched one tile ahead.
 //
-// The loop is VALU-bound (softmax), not MFMA-bound, at d = 32 .. 80, so the per-key VALU work is cut to its essentials:
+// The loop's time is VALU time PLUS MFMA time: on this chip a SIMD does not run plain VALU work under its own (or its other
+// wave's) MFMAs -- tools/micro/mfma_valu_overlap.hip: 12 MFMAs 183 ns, 84 fma 98 ns, finely interleaved 291 ns; only v_exp
+// overlaps, partly.  A software-pipelined loop (next tile's S' MFMAs and this tile's P V MFMAs spread over the exponentials, all
+// LDS fragments requested a phase early) therefore measured 22.5 us against 22.3 at N = 1000 and was dropped; what counts is
+// the instruction count of each kind.  So the per-key VALU work is cut to its essentials:
 //   * the running maximum enters as the INITIAL ACCUMULATOR of the S^T MFMAs (S' = K Q^T - m), so p = exp2(S') needs no
 //     per-element subtraction; the maximum is only raised when a tile exceeds it by more than RESCALE_THR (deferred rescale,
 //     wave-uniform branch) -- P is then bounded by 2^THR instead of 1, which fp32 accumulation and bf16 P tolerate
@@ -130,37 +134,53 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // two register sets: the loads of tile-group it+2 are issued at the top of iteration it and written to LDS at the bottom of
   // iteration it+1 -- two iterations of flight time (one iteration, ~0.5 us, does not cover an L2 miss)
   bf16x8 kreg[2][SP][KPT], vreg[2][SP][VPT];
-  auto prefetch = [&](int kvbase, auto setc) {
+  // K / V^T tiles travel global -> registers -> LDS.  Buffer loads with the predicate folded into the descriptor's bound (an
+  // out-of-range offset returns zeros): a predicated plain load compiles to a branch plus `s_waitcnt vmcnt(0)` in front of the
+  // select, which would make every iteration wait for the tile requested one iteration earlier.
+  // The per-lane byte offsets never change (loop-invariant VGPRs); the tile advance and the "keys < Nk" bound live in the
+  // descriptor, rebuilt per tile with a few scalar instructions.  (An offset computed per tile ends up in the load's own
+  // destination register, and writing that while the previous load into it is in flight costs an `s_waitcnt vmcnt(0)`.)
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned k_off[KPT], v_off[VPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int cidx = tid + i * T;
+    const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
+    k_off[i] = (cidx < KCH && ch * 8 < D) ? (unsigned)row * (unsigned)(ldk * 2) + ch * 16 : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int cidx = tid + i * T;
+    const int row = cidx >> 3, ch = cidx & 7;
+    v_off[i] = (cidx < VCH && row < D) ? (unsigned)row * (unsigned)(vt_ld * 2) + ch * 16 : OOB;
+  }
+  auto prefetch_k = [&](int kvbase, auto setc) {
    constexpr int SET = decltype(setc)::value;
 #pragma unroll
    for (int j = 0; j < SP; ++j) {
     const int kv0 = kvbase + j * KV;
+    // rows kv0 .. Nk-1 of this head's K: the last valid byte is the end of row Nk-1's D columns
+    const int bytes = max(0, ((Nk - kv0 - 1) * ldk + D) * 2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(kb + (long long)kv0 * ldk), 0, kv0 < Nk ? bytes : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      const int cidx = tid + i * T;
-      const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
-      bf16x8 v = zero8;
-      if (cidx < KCH && kv0 + row < Nk && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(kb + (long long)(kv0 + row) * ldk + ch * 8);
-      kreg[SET][j][i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int cidx = tid + i * T;
-      const int row = cidx >> 3, ch = cidx & 7;
-      bf16x8 v = zero8;
-      const int kvb = kv0 + ch * 8;
-      if (cidx < VCH && row < D && kvb < Nk) {
-        v = *reinterpret_cast<const bf16x8*>(vb + (long long)row * vt_ld + kvb);
-        if (kvb + 8 > Nk) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) if (kvb + j >= Nk) v[j] = (bf16)0.f;
-        }
-      }
-      vreg[SET][j][i] = v;
-    }
+    for (int i = 0; i < KPT; ++i) kreg[SET][j][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, k_off[i], 0, 0));
    }
   };
-  auto stage = [&](int buf, auto setc) {
+  auto prefetch_v = [&](int kvbase, auto setc) {
+   constexpr int SET = decltype(setc)::value;
+#pragma unroll
+   for (int j = 0; j < SP; ++j) {
+    const int kv0 = kvbase + j * KV;
+    // columns kv0 .. of this head's V^T rows; the bound is the end of the head's last row (a chunk that starts inside the row
+    // padding or runs into the next row reads defined memory: stage_v clears every key >= Nk)
+    const int bytes = max(0, (D * vt_ld - kv0) * 2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(vb + kv0), 0, kv0 < Nk ? bytes : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) vreg[SET][j][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, v_off[i], 0, 0));
+   }
+  };
+  auto prefetch = [&](int kvbase, auto setc) { prefetch_k(kvbase, setc); prefetch_v(kvbase, setc); };
+  auto stage_k = [&](int buf, auto setc) {
    constexpr int SET = decltype(setc)::value;
 #pragma unroll
    for (int j = 0; j < SP; ++j) {
@@ -170,20 +190,33 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
       if (cidx < KCH) *reinterpret_cast<bf16x8*>(Ks + (buf * SP + j) * Cfg::KBYTES + row * KS + ch * 16) = kreg[SET][j][i];
     }
+   }
+  };
+  auto stage_v = [&](int buf, auto setc, int kvbase) {
+   constexpr int SET = decltype(setc)::value;
+#pragma unroll
+   for (int j = 0; j < SP; ++j) {
+    const int kv0 = kvbase + j * KV;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int cidx = tid + i * T;
       const int row = cidx >> 3, ch = cidx & 7;
       if (cidx < VCH) {
+        bf16x8 v = vreg[SET][j][i];
+        if (kv0 + KV > Nk) {                       // (wave-uniform) the tile that holds key Nk - 1: clear what lies beyond it --
+#pragma unroll                                     //  p = 0 there, but those bytes are row padding / the next row, not zeros
+          for (int e = 0; e < 8; ++e) if (kv0 + ch * 8 + e >= Nk) v[e] = (bf16)0.f;
+        }
         // rows are 136 B apart: 8-byte aligned only -> two 8-byte stores
         uint2* dst = reinterpret_cast<uint2*>(Vs + (buf * SP + j) * Cfg::VBYTES + row * VS + ch * 16);
-        const uint4 u = __builtin_bit_cast(uint4, vreg[SET][j][i]);
+        const uint4 u = __builtin_bit_cast(uint4, v);
         dst[0] = make_uint2(u.x, u.y);
         dst[1] = make_uint2(u.z, u.w);
       }
     }
    }
   };
+  auto stage = [&](int buf, auto setc, int kvbase) { stage_k(buf, setc); stage_v(buf, setc, kvbase); };
 
   f32x16 o[DT];
 #pragma unroll
@@ -196,25 +229,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   const int niter = (ntiles + SP - 1) / SP;
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
-  prefetch(0, Set0{});
-  if (niter > 1) prefetch(SP * KV, Set1{});
-  stage(0, Set0{});
-  // Drain every global load issued so far (Q fragments, both prefetch sets) HERE, with the builtin the compiler's wait-count pass
-  // models: otherwise the first use of the Q fragments inside the loop gets an `s_waitcnt vmcnt(0)` that, from the second
-  // iteration on, waits for the K / V^T prefetch issued a few instructions earlier -- a full L2 round trip exposed per tile, in
-  // every wave at once (the ISA showed exactly that).  vmcnt = 0, expcnt / lgkmcnt untouched.
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
 
-  auto iteration = [&](int it, auto curc) {     // curc: the register set that is free (its tile-group was staged last iteration)
-    constexpr int CUR = decltype(curc)::value;
-    const int buf = (it & 1) * SP + grp, kv0 = (it * SP + grp) * KV;
-    const bool first = it == 0;
-    if (it + 2 < niter) prefetch((it + 2) * SP * KV, curc);
-    if (SP == 1 || kv0 < Nk) {                 // (wave-uniform) a group past the last tile of an odd count sits this one out
-
-    // ---- S' = K Q^T (- m_run as the initial accumulator when the scores come out of the MFMA already scaled) ----
-    f32x16 s[2];
+  // ---- S' = K Q^T (- m_run as the initial accumulator when the scores come out of the MFMA already scaled) ----
+  auto scores = [&](int it, f32x16 (&s)[2]) {
+    const int buf = (it & 1) * SP + grp;
     const float acc0 = PRESCALED ? -m_run : 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -226,6 +244,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
       }
     }
+  };
+  // ---- online softmax of tile `it` (scores in s) and O^T += V^T P^T ----
+  auto softmax_pv = [&](int it, f32x16 (&s)[2]) {
+    const int buf = (it & 1) * SP + grp, kv0 = (it * SP + grp) * KV;
+    const bool first = it == 0;
     if (kv0 + KV > Nk) {  // tail tile: mask keys >= Nk
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
           if (kvr >= Nk) s[sub][i] = -INFINITY;
         }
     }
-    // ---- online softmax (lane-local: this lane's query column), deferred rescale ----
+    // lane-local: this lane's query column; deferred rescale
     float mx0 = max3f(s[0][0], s[0][1], s[0][2]), mx1 = max3f(s[1][0], s[1][1], s[1][2]);   // two independent chains
 #pragma unroll
     for (int i = 3; i < 15; i += 2) {
@@ -285,8 +308,31 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[t], 0, 0, 0);
       }
+  };
+  // (wave-uniform) a key group past the last tile of an odd count sits that iteration out
+  auto mine = [&](int it) { return SP == 1 || (it * SP + grp) * KV < Nk; };
+
+  prefetch(0, Set0{});
+  prefetch(SP * KV, Set1{});
+  stage(0, Set0{}, 0);
+  // Drain every global load issued so far (Q fragments, both prefetch sets) HERE, with the builtin the compiler's wait-count pass
+  // models: otherwise the first use of the Q fragments inside the loop gets an `s_waitcnt vmcnt(0)` that, from the second
+  // iteration on, waits for the K / V^T prefetch issued a few instructions earlier -- a full L2 round trip exposed per tile, in
+  // every wave at once (the ISA showed exactly that).  vmcnt = 0, expcnt / lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  // two register sets: the loads of tile-group it+2 are issued at the top of iteration it and written to LDS at the bottom of
+  // iteration it+1 -- two iterations of flight time (one iteration, ~0.5 us, does not cover an L2 miss)
+  auto iteration = [&](int it, auto curc) {     // curc: the register set that is free (its tile-group was staged last iteration)
+    constexpr int CUR = decltype(curc)::value;
+    prefetch((it + 2) * SP * KV, curc);         // (unconditional: past the last tile the descriptor's bound is 0 -> zeros, no traffic;
+                                                //  a fixed number of loads per iteration lets the compiler count them in s_waitcnt)
+    if (mine(it)) {
+      f32x16 s[2];
+      scores(it, s);
+      softmax_pv(it, s);
     }
-    if (it + 1 < niter) stage((it & 1) ^ 1, std::integral_constant<int, CUR ^ 1>{});
+    if (it + 1 < niter) stage((it & 1) ^ 1, std::integral_constant<int, CUR ^ 1>{}, (it + 1) * SP * KV);
     __syncthreads();
   };
   for (int it = 0; it < niter; it += 2) {
