@@ -91,7 +91,7 @@ PROTOTYPES = {
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                       C.c_void_p]),
+                                       C.c_void_p, C.c_void_p]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                  C.c_void_p]),
     "aldm_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,

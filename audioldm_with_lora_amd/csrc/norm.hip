@@ -404,6 +404,8 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(const long long* _
 // folds the partials of its image into per-group mean / rstd (a few KB from L2) and then streams its slab of pixels row by row
 // with 16-byte accesses -- no strip-per-workgroup mapping (8 bytes out of every pixel row, 16 workgroups touching every line), no
 // block reductions over the data.
+constexpr int ALDM_GN_FINALIZE_MIN_TILES = 96;
+
 struct GnSrc {
   const bf16* x; const float* tab;
   int C;        // channels of this source
@@ -411,34 +413,74 @@ struct GnSrc {
   int tpi;      // > 0: tiles are image-aligned, `tpi` per image, slot 0 only (halo kernels)
 };
 
+// (sum, sum of squares) of group g of image b from the producers' per-tile tables: lane j of the group's lpg lanes takes tiles
+// t0 + j, t0 + j + lpg, ...  Four tiles per round with independent loads: a one-tile-per-iteration loop is a chain of L2 round
+// trips (HW = 4000: 8 of them per lane, half the launch's time; a VAE image of 65536 pixels has 512 tiles).
+__device__ __forceinline__ void gn_source_sums(const GnSrc& s, int b, int HW, int qa, int nq, int j, int lpg, float& a, float& q2) {
+  const int Q = s.C >> 2;
+  int t0, t1;
+  if (s.tpi > 0) { t0 = b * s.tpi; t1 = t0 + s.tpi - 1; }
+  else { t0 = (b * HW) / s.bm; t1 = ((b + 1) * HW - 1) / s.bm; }
+  float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = t0 + j; t <= t1; t += 4 * lpg) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tt = min(t + u * lpg, t1);                   // (clamped: always a valid address; the weight below drops repeats)
+      const float w = (t + u * lpg <= t1) ? 1.f : 0.f;
+      const int slot = (s.tpi > 0) ? 0 : (((tt * s.bm) / HW) != b);
+      const float* row = s.tab + ((long long)(tt * 2 + slot) * Q + qa) * 2;
+      for (int k = 0; k < nq; ++k) {
+        const float2 v = *reinterpret_cast<const float2*>(row + 2 * k);
+        a4[u] = fmaf(w, v.x, a4[u]);
+        q4[u] = fmaf(w, v.y, q4[u]);
+      }
+    }
+  }
+  a += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  q2 += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+}
+// a group of the concatenation may take its first channels from source 1 and the rest from source 2 (256 + 128 channels in 32
+// groups of 12: group 21 is channels 252 .. 263); the 4-channel quads never straddle (C1 % 4 == 0)
+__device__ __forceinline__ void gn_group_sums(const GnSrc& s1, const GnSrc& s2, int b, int HW, int Cg, int g, int j, int lpg, float& a, float& q2) {
+  const int c0 = g * Cg, c1 = c0 + Cg;
+  if (c0 < s1.C) gn_source_sums(s1, b, HW, c0 >> 2, (min(c1, s1.C) - c0) >> 2, j, lpg, a, q2);
+  if (c1 > s1.C) {
+    const int lo = max(c0, s1.C);
+    gn_source_sums(s2, b, HW, (lo - s1.C) >> 2, (c1 - lo) >> 2, j, lpg, a, q2);
+  }
+}
+
+// mean / rstd per (image, group) into ws [B][64][2], one workgroup per image: the stand-alone first phase of aldm_groupnorm_apply for
+// images of many tiles (every apply workgroup summing every tile of its image costs more than the pixels it then normalises)
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(GnSrc s1, GnSrc s2, int HW, int groups, float eps, int lpg, float* __restrict__ ws) {
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int Cg = (s1.C + s2.C) / groups;
+  const int g = tid / lpg, j = tid - g * lpg;
+  float a = 0.f, q2 = 0.f;
+  if (g < groups) gn_group_sums(s1, s2, b, HW, Cg, g, j, lpg, a, q2);
+  for (int o = 1; o < lpg; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
+  if (g < groups && j == 0) {
+    const float n = (float)HW * (float)Cg;
+    const float mu = a / n;
+    ws[(b * 64 + g) * 2] = mu;
+    ws[(b * 64 + g) * 2 + 1] = rsqrtf(fmaxf(q2 / n - mu * mu, 0.f) + eps);
+  }
+}
+
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnSrc s1, GnSrc s2, int HW, int groups, float eps,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                              bf16* __restrict__ y, int pxb, int lpg, AldmDiv dupp) {
+                                                              bf16* __restrict__ y, int pxb, int lpg, AldmDiv dupp, const float* __restrict__ ws) {
   __shared__ float sm[64], sr[64];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int C = s1.C + s2.C, Cg = C / groups;
-  // ---- statistics: lpg lanes per group, each sums a share of the image's tiles ----
-  {
+  if (ws) {                                                  // statistics already final (groupnorm_finalize_kernel)
+    if (tid < groups) { sm[tid] = ws[(b * 64 + tid) * 2]; sr[tid] = ws[(b * 64 + tid) * 2 + 1]; }
+  } else {
+    // ---- statistics: lpg lanes per group, each sums a share of the image's tiles ----
     const int g = tid / lpg, j = tid - g * lpg;
     float a = 0.f, q2 = 0.f;
-    if (g < groups) {
-      const int c0 = g * Cg;
-      const GnSrc& s = c0 < s1.C ? s1 : s2;
-      const int qa = (c0 < s1.C ? c0 : c0 - s1.C) >> 2, nq = Cg >> 2, Q = s.C >> 2;
-      int t0, t1;
-      if (s.tpi > 0) { t0 = b * s.tpi; t1 = t0 + s.tpi - 1; }
-      else { t0 = (b * HW) / s.bm; t1 = ((b + 1) * HW - 1) / s.bm; }
-      for (int t = t0 + j; t <= t1; t += lpg) {
-        const int slot = (s.tpi > 0) ? 0 : (((t * s.bm) / HW) != b);
-        const float* row = s.tab + ((long long)(t * 2 + slot) * Q + qa) * 2;
-        for (int k = 0; k < nq; ++k) {
-          const float2 v = *reinterpret_cast<const float2*>(row + 2 * k);
-          a += v.x;
-          q2 += v.y;
-        }
-      }
-    }
+    if (g < groups) gn_group_sums(s1, s2, b, HW, Cg, g, j, lpg, a, q2);
     for (int o = 1; o < lpg; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
     if (g < groups && j == 0) {
       const float n = (float)HW * (float)Cg;
@@ -470,17 +512,26 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnSrc s1, GnSrc s2
     const bool first = c < s1.C;
     const bf16* src = first ? s1.x + c : s2.x + (c - s1.C);
     const int Cs = first ? s1.C : s2.C;
-    for (int pl = pl0; pl < np; pl += ppp) {
-      const long long pix = (long long)b * HW + p0 + pl;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * Cs);
-      bf16x8 o;
+    // four pixels per round, their loads issued together: a load / compute / store loop is one memory round trip per pixel, and
+    // a 4000-pixel image gives a CU one workgroup (one wave per SIMD) to hide it with -- 2 TB/s
+    const long long pix0 = (long long)b * HW + p0;
+    for (int pl = pl0; pl < np; pl += 4 * ppp) {
+      bf16x8 v[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float t = fmaf((float)v[k], sc[k], sh[k]);
-        if (act == ALDM_ACT_SILU) t = silu_f(t);
-        o[k] = (bf16)t;
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(src + (pix0 + min(pl + u * ppp, np - 1)) * Cs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (pl + u * ppp < np) {
+          bf16x8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float t = fmaf((float)v[u][k], sc[k], sh[k]);
+            if (act == ALDM_ACT_SILU) t = silu_f(t);
+            o[k] = (bf16)t;
+          }
+          *reinterpret_cast<bf16x8*>(y + (pix0 + pl + u * ppp) * C + c) = o;
+        }
       }
-      *reinterpret_cast<bf16x8*>(y + pix * C + c) = o;
     }
   }
 }
@@ -566,12 +617,12 @@ extern "C" int aldm_embed_layernorm(const long long* ids, int B, int L, int C, c
 
 extern "C" int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, int tpi, const void* x2, const float* qstat2, int bm2,
                                     int tpi2, int B, int HW, int C1, int C2, int groups, float eps, const float* gamma,
-                                    const float* beta, int act, void* y, void* stream) {
+                                    const float* beta, int act, void* y, float* stat_ws, void* stream) {
   ALDM_CHECK_ARG(x && qstat && y && gamma && beta, "groupnorm_apply: null pointer");
   ALDM_CHECK_ARG(B > 0 && HW > 0 && C1 > 0 && C2 >= 0 && groups > 0 && groups <= 64 && (C2 == 0 || (x2 && qstat2)), "groupnorm_apply: bad dims");
   const int C = C1 + C2;
-  ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % (C / groups) == 0 && C1 % 8 == 0 && C2 % 8 == 0,
-                 "groupnorm_apply: group width %d must be a multiple of 4 that divides C1 = %d; C1, C2 multiples of 8", C / groups, C1);
+  ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 8 == 0 && C2 % 8 == 0,
+                 "groupnorm_apply: group width %d must be a multiple of 4; C1 = %d, C2 = %d multiples of 8", C / groups, C1, C2);
   ALDM_CHECK_ARG(C / 8 <= 256, "groupnorm_apply: at most 2048 channels (a workgroup walks %d 16-byte units per pixel with 256 threads)", C / 8);
   ALDM_CHECK_ARG((tpi > 0 || (bm > 0 && bm <= HW)) && (C2 == 0 || tpi2 > 0 || (bm2 > 0 && bm2 <= HW)),
                  "groupnorm_apply: an M-tile of the producer may span at most two images (tile rows <= H*W)");
@@ -580,7 +631,14 @@ extern "C" int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, i
   int pxb = 16;
   while (pxb < 256 && pxb * C * 2 < 32768) pxb *= 2;         // ~32 KB of pixels per workgroup
   GnSrc s1{(const bf16*)x, qstat, C1, bm, tpi}, s2{(const bf16*)x2, qstat2, C2, bm2, tpi2};
+  // tiles per image the statistics phase walks; past ALDM_GN_FINALIZE_MIN_TILES a one-workgroup-per-image launch sums them once
+  const int tiles = max(tpi > 0 ? tpi : HW / bm + 1, C2 ? (tpi2 > 0 ? tpi2 : HW / bm2 + 1) : 0);
+  const bool two_phase = stat_ws && tiles >= ALDM_GN_FINALIZE_MIN_TILES;
+  if (two_phase) {
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, s1, s2, HW, groups, eps, lpg, stat_ws);
+    if (int rc = aldm_launch_status("groupnorm_finalize")) return rc;
+  }
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(cdiv(HW, pxb), B), dim3(256), 0, (hipStream_t)stream, s1, s2, HW, groups, eps, gamma,
-                     beta, act, (bf16*)y, pxb, lpg, aldm_make_div((unsigned)(C >> 3)));
+                     beta, act, (bf16*)y, pxb, lpg, aldm_make_div((unsigned)(C >> 3)), two_phase ? (const float*)stat_ws : nullptr);
   return aldm_launch_status("groupnorm_apply");
 }

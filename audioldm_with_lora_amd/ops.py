@@ -367,6 +367,9 @@ def _workspace(nbytes, device):
     return t
 
 
+GN_FINALIZE_MIN_TILES = 96          # = ALDM_GN_FINALIZE_MIN_TILES (csrc/norm.hip)
+
+
 @dataclass
 class QStats:
     """GroupNorm statistics a convolution left next to its output (aldm_igemm qstat_out): per M-tile, image slot and 4-channel quad
@@ -774,13 +777,16 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     n = B * H * W * (C1 + C2)
     q1, q2 = getattr(x, "qstats", None), (getattr(x2, "qstats", None) if x2 is not None else None)
     Cg = (C1 + C2) // groups
-    if (q1 is not None and (x2 is None or q2 is not None) and (C1 + C2) % groups == 0 and Cg % 4 == 0 and C1 % Cg == 0
+    if (q1 is not None and (x2 is None or q2 is not None) and (C1 + C2) % groups == 0 and Cg % 4 == 0
             and C1 % 8 == 0 and C2 % 8 == 0 and groups <= 64 and (C1 + C2) // 8 <= 256
             and x.is_contiguous() and (x2 is None or x2.is_contiguous())):
         # one coalesced pass: the producing convolution(s) handed the statistics over
+        # big images (the VAE's mels): the (mean, rstd) table is summed once, by a launch of its own, instead of by every workgroup
+        tiles = max(q.tpi if q.tpi > 0 else H * W // q.bm + 1 for q in (q1, q2) if q is not None)
+        ws = torch.empty(B, 64, 2, dtype=torch.float32, device=x.device) if tiles >= GN_FINALIZE_MIN_TILES else None
         check(_launch(f"groupnorm_apply|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm_apply(
             _p(x), _p(q1.table), q1.bm, q1.tpi, _p(x2), _p(q2.table) if q2 is not None else None, q2.bm if q2 is not None else 0,
-            q2.tpi if q2 is not None else 0, B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())),
+            q2.tpi if q2 is not None else 0, B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _p(ws), _stream())),
             "aldm_groupnorm_apply")
         return y
     check(_launch(f"groupnorm|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(

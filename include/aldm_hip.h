@@ -182,10 +182,12 @@ int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2,
 /* GroupNorm (+SiLU) over cat[x, x2] in ONE coalesced pass, with the statistics handed over by the aldm_igemm launches that
    produced x (and x2): qstat / qstat2 are their qstat_out tables; bm = rows per M-tile of the producing launch (generic
    tiles, bm <= HW), or tpi > 0 = tiles per image of an image-aligned (halo) launch.  Same arithmetic as aldm_groupnorm
-   (F.group_norm under ResnetBlock2D.norm1/2, conv_norm_out, the VAE's norms), variance as E[x^2] - mean^2 in fp32. */
+   (F.group_norm under ResnetBlock2D.norm1/2, conv_norm_out, the VAE's norms), variance as E[x^2] - mean^2 in fp32.
+   stat_ws (fp32 [B][64][2], may be NULL): scratch for the (mean, rstd) table; with it, images of >= 96 producer tiles (the VAE's
+   65536-pixel mel images) get their statistics summed ONCE by a one-workgroup-per-image launch in front of the apply pass. */
 int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, int tpi, const void* x2, const float* qstat2, int bm2, int tpi2,
                          int B, int HW, int C1, int C2, int groups, float eps, const float* gamma, const float* beta, int act,
-                         void* y, void* stream);
+                         void* y, float* stat_ws, void* stream);
 
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
 int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,

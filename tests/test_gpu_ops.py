@@ -305,6 +305,10 @@ def test_groupnorm(ops, B, HW, C1, C2, groups, act):
     (2, 250, 16, 128, 0, 32, 3),
     (2, 250, 16, 128, 0, 32, 4),
     (2, 128, 16, 128, 0, 32, 8),       # halo 64x128
+    (2, 250, 16, 256, 128, 32, 0),     # Cg = 12 and C1 % 12 != 0: group 21 takes channels 252..255 from x and 0..7 from x2 (UNet up block 3)
+    (2, 250, 16, 384, 256, 32, 0),     # Cg = 20: group 19 straddles the concatenation
+    (1, 1024, 16, 128, 0, 32, 2),      # 256 producer tiles per image: the statistics are summed once by the finalize launch
+    (2, 512, 16, 128, 128, 32, 0),     # two sources, >= 96 tiles each (finalize with a concatenation)
 ])
 def test_groupnorm_apply_from_conv_statistics(ops, B, H, W, C1, C2, groups, tile):
     """GroupNorm whose statistics were handed over by the producing convolutions (aldm_igemm qstat_out ->
