@@ -37,16 +37,20 @@ struct RowRegs { static constexpr int CH = TS * (DP / 8), NR = (CH + T - 1) / T;
 template <int DP, int T>
 struct TokRegs { static constexpr int CH = BwdCfg<DP>::DT * 32 * (TS / 8), NR = (CH + T - 1) / T; bf16x8 v[NR]; };
 
+// Buffer loads with every predicate folded into the descriptor's bound or the offset (out of range -> zeros): a predicated plain
+// load compiles to a branch with an `s_waitcnt vmcnt(0)` at the join, which serialises the tile's loads with each other.
 template <int DP, int T>
 __device__ __forceinline__ void fetch_rows(RowRegs<DP, T>& rg, const bf16* base, int ld, int t0, int N, int D, int tid) {
   using R = RowRegs<DP, T>;
+  // rows t0 .. N-1, D columns each: the last valid byte is the end of row N-1's D columns
+  const int bytes = t0 < N ? ((N - t0 - 1) * ld + D) * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base + (long long)t0 * ld), 0, bytes, 0x00020000);
 #pragma unroll
   for (int i = 0; i < R::NR; ++i) {
     const int c = tid + i * T;
     const int row = c / (DP / 8), ch = c - row * (DP / 8);
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < R::CH && t0 + row < N && ch * 8 < D) v = *reinterpret_cast<const bf16x8*>(base + (long long)(t0 + row) * ld + ch * 8);
-    rg.v[i] = v;
+    const unsigned off = (c < R::CH && ch * 8 < D) ? (unsigned)row * (unsigned)(ld * 2) + ch * 16 : 0x80000000u;
+    rg.v[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
   }
 }
 template <int DP, int T>
@@ -63,14 +67,16 @@ __device__ __forceinline__ void store_rows(char* dst, const RowRegs<DP, T>& rg, 
 template <int DP, int T>
 __device__ __forceinline__ void fetch_tokmajor(TokRegs<DP, T>& rg, const bf16* base, int ldt, int t0, int N, int D, int tid) {
   using R = TokRegs<DP, T>;
+  // columns t0 .. of the D token-major rows; bound = end of the last row (a chunk inside the row padding or running into the next row
+  // reads defined memory: store_tokmajor clears every token >= N)
+  const int bytes = t0 < N ? (D * ldt - t0) * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base + t0), 0, bytes, 0x00020000);
 #pragma unroll
   for (int i = 0; i < R::NR; ++i) {
     const int c = tid + i * T;
     const int row = c >> 3, ch = c & 7;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int tb = t0 + ch * 8;
-    if (c < R::CH && row < D && tb < N) v = *reinterpret_cast<const bf16x8*>(base + (long long)row * ldt + tb);
-    rg.v[i] = v;
+    const unsigned off = (c < R::CH && row < D) ? (unsigned)row * (unsigned)(ldt * 2) + ch * 16 : 0x80000000u;
+    rg.v[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
   }
 }
 template <int DP, int T>
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
   fetch_rows<DP, T>(rk, kb, ld, 0, N, D, tid);
   fetch_rows<DP, T>(rv, vb, ld, 0, N, D, tid);
   fetch_tokmajor<DP, T>(rkt, ktb, ldt, 0, N, D, tid);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                   // (as in attn_bwd_dkv_kernel: Q / dO fragments, lse, delta and tile 0 are waited for here)
   for (int it = 0; it < ntiles; ++it) {
     const int kv0 = it * TS;
     __syncthreads();                                    // every wave is done with the previous tile's LDS images
@@ -186,11 +193,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
     store_rows<DP, T>(Vs, rv, tid);
     store_tokmajor<DP, T>(KTs, rkt, kv0, N, tid);
     __syncthreads();
-    if (it + 1 < ntiles) {                              // next tile: loads in flight under this tile's MFMAs
-      fetch_rows<DP, T>(rk, kb, ld, kv0 + TS, N, D, tid);
-      fetch_rows<DP, T>(rv, vb, ld, kv0 + TS, N, D, tid);
-      fetch_tokmajor<DP, T>(rkt, ktb, ldt, kv0 + TS, N, D, tid);
-    }
+    // next tile: loads in flight under this tile's MFMAs (past the last tile the descriptors' bounds are 0: zeros, no traffic)
+    fetch_rows<DP, T>(rk, kb, ld, kv0 + TS, N, D, tid);
+    fetch_rows<DP, T>(rv, vb, ld, kv0 + TS, N, D, tid);
+    fetch_tokmajor<DP, T>(rkt, ktb, ldt, kv0 + TS, N, D, tid);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -204,11 +210,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
       }
       bf16x8 dsf[2];
+      if (kv0 + TS > N) {                               // (wave-uniform) only the tile that holds key N - 1 masks: keys >= N are zero
+#pragma unroll                                          //  rows of K, whose p = exp2(-L) is not zero
+        for (int i = 0; i < 16; ++i) {
+          const int kvr = kv0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const float p = kvr < N ? __builtin_amdgcn_exp2f(fmaf(s[i], c, -L)) : 0.f;
+          dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - dl));
+        }
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int kvr = kv0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float p = kvr < N ? __builtin_amdgcn_exp2f(fmaf(s[i], c, -L)) : 0.f;
-        dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - dl));
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -L));
+          dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - dl));
+        }
       }
 #pragma unroll
       for (int t = 0; t < DT; ++t)
@@ -288,17 +302,25 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const bf16* __res
   RowRegs<DP, T> rq, rdo;
   TokRegs<DP, T> rqt, rdot;
   float rl = 0.f, rd = 0.f;                             // lse / delta of query tid of the tile (threads < TS)
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lb), 0, N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, N * 4, 0x00020000);
   auto fetch_tile = [&](int qt0) {
     fetch_rows<DP, T>(rq, qb, ld, qt0, N, D, tid);
     fetch_rows<DP, T>(rdo, dob, ldo, qt0, N, D, tid);
     fetch_tokmajor<DP, T>(rqt, qtb, ldt, qt0, N, D, tid);
     fetch_tokmajor<DP, T>(rdot, dotb, ldt, qt0, N, D, tid);
-    if (tid < TS) {
-      rl = qt0 + tid < N ? lb[qt0 + tid] : 0.f;
-      rd = qt0 + tid < N ? db[qt0 + tid] : 0.f;
+    {
+      const unsigned off = tid < TS ? (unsigned)(qt0 + tid) * 4u : 0x80000000u;           // (beyond N: out of range -> 0)
+      const float l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_l, off, 0, 0));
+      rd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, off, 0, 0));
+      rl = qt0 + tid < N ? l : 3.0e38f;                 // padding queries: exp2(s c - 3e38) = 0, so P and dS need no mask
     }
   };
   fetch_tile(0);
+  // Drain the loads issued so far (the K / V fragments above, tile 0) HERE: otherwise the compiler places the wait for the K / V
+  // fragments in front of the loop's first MFMA as `s_waitcnt vmcnt(0)`, where from the second iteration on it waits for the NEXT
+  // tile's loads issued a few instructions earlier -- the prefetch then hides nothing (the ISA showed exactly that).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   for (int it = 0; it < ntiles; ++it) {
     const int qt0 = it * TS;
     __syncthreads();                                    // every wave is done with the previous tile's LDS images
@@ -308,7 +330,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const bf16* __res
     store_tokmajor<DP, T>(dOTs, rdot, qt0, N, tid);
     if (tid < TS) { Ls[tid] = rl; Ds[tid] = rd; }
     __syncthreads();
-    if (it + 1 < ntiles) fetch_tile(qt0 + TS);          // next tile: loads in flight under this tile's MFMAs
+    fetch_tile(qt0 + TS);                               // next tile: loads in flight under this tile's MFMAs (past the last tile the
+                                                        // descriptors' bounds are 0: zeros, no traffic -- and a fixed load count per iteration)
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -323,11 +346,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const bf16* __res
       }
       bf16x8 pf[2], dsf[2];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ql = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;     // query row inside the staged tile
-        const float p = (qt0 + ql < N) ? __builtin_amdgcn_exp2f(fmaf(s[i], c, -Ls[ql])) : 0.f;
-        pf[i >> 3][i & 7] = (bf16)p;
-        dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - Ds[ql]));
+      for (int j = 0; j < 4; ++j) {
+        // accumulator registers 4j .. 4j+3 are query rows sub*32 + 8j + 4hh + (0..3) of the staged tile: one 16-byte LDS read each
+        // for lse and delta (every lane of a half-wave reads the same address: a broadcast)
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + sub * 32 + 8 * j + 4 * hh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + sub * 32 + 8 * j + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * j + e;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
+          pf[i >> 3][i & 7] = (bf16)p;
+          dsf[i >> 3][i & 7] = (bf16)(p * (dp[i] - d4[e]));
+        }
       }
 #pragma unroll
       for (int t = 0; t < DT; ++t)

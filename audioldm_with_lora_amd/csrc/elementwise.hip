@@ -276,7 +276,7 @@ extern "C" int aldm_gaussian_sample(const float* params, const float* noise, int
 }
 
 extern "C" int aldm_sleep_us(int us, void* stream) {
-  ALDM_CHECK_ARG(us > 0 && us <= 2000000, "sleep_us: 0 < us <= 2e6");
+  ALDM_CHECK_ARG(us >= 0 && us <= 2000000, "sleep_us: 0 <= us <= 2e6");   // (0: an empty kernel -- bench.py times the graph's kernel boundary with it)
   hipLaunchKernelGGL(sleep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)us * 100ull);
   return aldm_launch_status("sleep_us");
 }

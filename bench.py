@@ -110,6 +110,46 @@ def trace_replays(engine, reps=6):
         return None, None
 
 
+def launch_floor_us(n=200, full_grid=False):
+    """Cost of one kernel boundary inside a replayed hipGraph: n launches captured back to back, replay time / n.  Default: a
+    one-wave kernel that does nothing (aldm_sleep_us(0)) -- the bare boundary.  full_grid: the cheapest USEFUL launch, a 512-workgroup
+    elementwise pass over 1 MB (fp32 -> bf16), i.e. boundary + filling and draining the whole chip once."""
+    from audioldm_with_lora_amd import ops
+    src = torch.zeros(512, 512, device="cuda")
+    dst = torch.empty(512, 512, dtype=torch.bfloat16, device="cuda")
+    one = (lambda: ops.f32_to_bf16(src, out=dst)) if full_grid else (lambda: ops.sleep_us(0))
+    one()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            one()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / n)
+    return best
+
+
+def floor_model(rows, step_ms, boundary_us, small_us):
+    """Where the step's time can NOT go away at this launch structure: every launch pays the graph's kernel boundary, then its own
+    roofline time max(flops / MFMA peak, algorithmic bytes / HBM peak).  `structure_floor_ms` keeps the 246-launch structure and
+    makes every kernel perfect; `fused_floor_ms` is the same work as ONE launch.  ms_per_step / structure_floor_ms is the number
+    to push towards 1 by kernel work; structure_floor_ms itself only moves by removing launches."""
+    roof_us = sum(max(r[1] / (PEAK_BF16_TFLOPS * 1e6), r[2] / (PEAK_HBM_GBS * 1e3)) for r in rows)
+    n = len(rows)
+    structure = n * boundary_us + roof_us
+    return {"launches": n, "boundary_us_per_launch": round(boundary_us, 2), "boundaries_ms": round(n * boundary_us / 1e3, 3),
+            "smallest_useful_launch_us": round(small_us, 2), "launches_at_smallest_ms": round(n * small_us / 1e3, 3),
+            "roofline_sum_ms": round(roof_us / 1e3, 3), "structure_floor_ms": round(structure / 1e3, 3),
+            "fused_floor_ms": round((boundary_us + roof_us) / 1e3, 3),
+            "step_over_structure_floor": round(step_ms / (structure / 1e3), 2),
+            "peaks": {"mfma_bf16_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS}}
+
+
 def join_trace(rows, kernels):
     """Attach the traced kernel durations to the launch rows (same launch order; a split-K igemm call is two kernels)."""
     out, k = [], 0
@@ -495,6 +535,8 @@ def main():
             rows = [(l, f, b, e, s, e, [(l.split("|")[0], e)]) for l, f, b, e, s in ev_rows]
             print("[bench] per-kernel durations fall back to hipEvent pairs", file=sys.stderr)
 
+    boundary_us = launch_floor_us() if rank == 0 else 0.0
+    small_us = launch_floor_us(full_grid=True) if rank == 0 else 0.0
     pipe_t = None
     if not args.no_train and rank == 0 and not args.fp8_attention and args.chains in (None, 1):
         pipe_t = bench_pipeline(unet, args.batch, 10.0, NSTEPS, G, seed_off=100 * rank)
@@ -547,6 +589,7 @@ def main():
                     "launches_per_step_total": len(rows), "kernel_time_sum_ms": round(total_us / 1e3, 4),
                     "graph_span_ms": round(span_us / 1e3, 4) if span_us else None,
                     "whole_step_tflops": round(8 * 101.2e9 * (args.batch / 4) / (dt / args.steps) / 1e12, 1)}
+        floor = floor_model(rows, dt / args.steps * 1e3, boundary_us, small_us)
         out = {
             "metric": "unet_denoise_steps_per_sec", "value": round(world * args.steps / dt, 3), "unit": "denoise_steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -557,6 +600,7 @@ def main():
                        "per_gpu_batch": args.batch, "parallelism": f"prompt-sharded x{world}", "hip_graph": not args.no_graph, "graph_chains": eng.chains,
                        "sample_steps_per_sec": round(world * args.steps * args.batch / dt, 2)},
             "roofline": roofline,
+            "floor": floor,
             "k1": {"what": "fused-LoRA attention module = QKV GEMM + LoRA (Q|K, V^T) -> flash attention -> out-proj + LoRA + residual; "
                            "kernel durations only (the two kernel boundaries inside a module are not counted)",
                    "flops": "b(8NC^2 + 4N^2C + 16NCr)", "bytes": "2bNCs + 4C^2 s + 8Crs, s = 2",
