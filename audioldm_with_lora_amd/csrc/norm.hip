@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int GN_THREADS = 512;
+constexpr int GN_MAXCG = 256;       // channels per group the register-strip kernels stage gamma / beta for (UNet: <= 80)
 constexpr int GN_LDS_QUADS = 16384;  // 128 KiB of bf16x4 strip cache
 
 __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nthreads) {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
                                                                    bf16* __restrict__ y, AldmDiv dqpp) {
   aldm_touch_kernargs<96>();                // 84 bytes of explicit arguments: both lines in one round (common.h)
   __shared__ float red[GN_THREADS / 64];
+  __shared__ __attribute__((aligned(16))) float sgm[GN_MAXCG], sbt[GN_MAXCG];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
   const int nb = gridDim.x / groups;
@@ -102,6 +104,9 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
   const int c0 = g * Cg;
   const int nquads = HW * qpp;
   const int tid = threadIdx.x;
+  // the group's gamma / beta go to LDS now, under the strip's loads (visible after the first reduction's barrier): fetched per
+  // output quad they were a load -> wait -> compute -> store chain of QPT L2 round trips at the END of the kernel
+  if (tid < Cg) { sgm[tid] = gamma[c0 + tid]; sbt[tid] = beta[c0 + tid]; }
 
   bf16x4 v[QPT];
   float s = 0.f;
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
     if (q < nquads) {
       const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(sgm + 4 * j);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(sbt + 4 * j);
       bf16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   // C = channels of the partial tiles (first source); C2 more channels come as plain bf16 from x2 (torch.cat([h, skip]) in
   // front of an up-block ResnetBlock2D's norm1).  A group lies wholly in one source (host-checked: C % group width == 0).
   __shared__ float red[GN_THREADS / 64];
+  __shared__ __attribute__((aligned(16))) float sgm[GN_MAXCG], sbt[GN_MAXCG], sadd[GN_MAXCG];
   const int Ct = C + C2;
   const int Cg = Ct / groups, qpp = Cg >> 2;
   const int nb = gridDim.x / groups;
@@ -175,6 +181,19 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   const int c0 = g * Cg;
   const int nquads = HW * qpp;
   const int tid = threadIdx.x;
+  // per-channel constants of the group through LDS, fetched under the partial tiles' loads: gamma, beta, and bias + this image's
+  // row bias as one addend (each used to be a load -> wait chain of its own behind the split-K sum)
+  if (tid < Cg) {
+    const int c = c0 + tid;
+    sgm[tid] = gamma[c];
+    sbt[tid] = beta[c];
+    float a = 0.f;
+    if (c < C) {
+      if (bias) a = bias[c];
+      if (rowbias) a += rowbias[(long long)b * rowbias_ld + c];
+    }
+    sadd[tid] = a;
+  }
 
   f32x4 v[QPT];
   bf16x4 rv[QPT];
@@ -211,25 +230,28 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
       }
     }
   }
-  for (; sp < splits; ++sp) {
+  if (sp < splits) {                           // 1 .. 3 partials left: requested together (one round trip), added in split order
+    const int rem = splits - sp;
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
       if (tid + i * GN_THREADS < nquads) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ws + off[i] + sp * sstride);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[i][k] += a[k];
+        const float* w0 = ws + off[i] + sp * sstride;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(w0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(w0 + (rem > 1 ? 1 : 0) * sstride);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(w0 + (rem > 2 ? 2 : 0) * sstride);
+        v[i] += a0;
+        if (rem > 1) v[i] += a1;
+        if (rem > 2) v[i] += a2;
       }
     }
   }
+  __syncthreads();                              // sadd / sgm / sbt are in LDS
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     if (tid + i * GN_THREADS < nquads) {
       const int c = ch[i];
-      if (!second) {
-        if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + c); v[i] += t; }
-        if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + (long long)b * rowbias_ld + c); v[i] += t; }
-      }
+      if (!second) v[i] += *reinterpret_cast<const f32x4*>(sadd + (c - c0));   // bias + row bias
       if (second || res) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[i][k] += (float)rv[i][k];
@@ -258,8 +280,8 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   for (int i = 0; i < QPT; ++i) {
     if (tid + i * GN_THREADS < nquads) {
       const int c = ch[i];
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(sgm + (c - c0));
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(sbt + (c - c0));
       bf16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -553,10 +575,11 @@ extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int 
 #define ALDM_GN_REG(QPT)                                                                                               \
   hipLaunchKernelGGL(groupnorm_reg_kernel<QPT>, dim3(B * groups), dim3(GN_THREADS), 0, (hipStream_t)stream,            \
                      (const bf16*)x, (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y, dq)
-  if (nquads <= 4 * GN_THREADS) ALDM_GN_REG(4);
-  else if (nquads <= 8 * GN_THREADS) ALDM_GN_REG(8);
-  else if (nquads <= 16 * GN_THREADS) ALDM_GN_REG(16);
-  else if (nquads <= 32 * GN_THREADS) ALDM_GN_REG(32);
+  const bool reg_ok = C / groups <= GN_MAXCG;                 // (the register-strip kernels keep the group's gamma / beta in LDS)
+  if (reg_ok && nquads <= 4 * GN_THREADS) ALDM_GN_REG(4);
+  else if (reg_ok && nquads <= 8 * GN_THREADS) ALDM_GN_REG(8);
+  else if (reg_ok && nquads <= 16 * GN_THREADS) ALDM_GN_REG(16);
+  else if (reg_ok && nquads <= 32 * GN_THREADS) ALDM_GN_REG(32);
   else
     hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16*)x,
                        (const bf16*)x2, HW, C1, C2, groups, eps, gamma, beta, act, (bf16*)y, dq);
@@ -574,6 +597,7 @@ extern "C" int aldm_groupnorm_partials(const float* ws, int splits, int B, int H
   ALDM_CHECK_ARG(Ct % groups == 0 && (Ct / groups) % 4 == 0 && C % (Ct / groups) == 0,
                  "groupnorm_partials: group width %d must be a multiple of 4 and divide the first source's %d channels", Ct / groups, C);
   ALDM_CHECK_ARG(!rowbias || rowbias_ld >= C, "groupnorm_partials: rowbias_ld");
+  ALDM_CHECK_ARG(Ct / groups <= GN_MAXCG, "groupnorm_partials: at most %d channels per group", GN_MAXCG);
   const long long nquads = (long long)HW * (Ct / groups / 4);
   ALDM_CHECK_ARG(nquads <= 8 * GN_THREADS, "groupnorm_partials: strip of %lld quads exceeds the register-resident limit %d", nquads, 8 * GN_THREADS);
   const AldmDiv dq = aldm_make_div((unsigned)(Ct / groups / 4));

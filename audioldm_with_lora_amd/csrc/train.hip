@@ -17,6 +17,8 @@ namespace {
 
 constexpr int GN_THREADS = 512;
 
+constexpr int GNB_MAXCG = 256;      // channels per group groupnorm_bwd stages gamma / beta for
+
 template <int NT = GN_THREADS>
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red, int tid) {
   a = wave_sum(a);
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
   // dy_ws: dY still as the split-K partial tiles [dy_splits][B*HW][C] (fp32) of the dX convolution that produced it
   // (aldm_igemm defer_reduce): summed here in split order and rounded to bf16, exactly what igemm_reduce_kernel would store
   __shared__ float red[32];
+  __shared__ __attribute__((aligned(16))) float sgm[GNB_MAXCG], sbt[GNB_MAXCG];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
   const int nb = gridDim.x / groups;
@@ -51,6 +54,9 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
   const int c0 = g * Cg;
   const int nquads = HW * qpp;
   const int tid = threadIdx.x;
+  // the group's gamma / beta through LDS (visible after the first reduction's barrier): read per element from global they were
+  // 4-byte loads with a wait each, in both sweeps
+  if (tid < Cg) { sgm[tid] = gamma[c0 + tid]; sbt[tid] = beta[c0 + tid]; }
 
   bf16x4 v[QPT], d[QPT];
   float s = 0.f, dummy = 0.f;
@@ -106,17 +112,17 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
     const int q = tid + i * NT;
     if (q < nquads) {
       const int j = q - aldm_div(q, dqpp) * qpp;
-      const int c = c0 + 4 * j;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(sgm + 4 * j), bt = *reinterpret_cast<const f32x4*>(sbt + 4 * j);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = ((float)v[i][k] - mean) * rstd;
         float dz = (float)d[i][k];
         if (act == ALDM_ACT_SILU) {
-          const float z = xh * gamma[c + k] + beta[c + k];
+          const float z = xh * gm[k] + bt[k];
           const float sg = sigmoid_f(z);
           dz *= sg * (1.f + z * (1.f - sg));
         }
-        const float gd = dz * gamma[c + k];
+        const float gd = dz * gm[k];
         s1 += gd;
         s2 += gd * xh;
       }
@@ -131,17 +137,18 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
     if (q < nquads) {
       const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(sgm + 4 * j), bt = *reinterpret_cast<const f32x4*>(sbt + 4 * j);
       bf16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = ((float)v[i][k] - mean) * rstd;
         float dz = (float)d[i][k];
         if (act == ALDM_ACT_SILU) {
-          const float z = xh * gamma[c + k] + beta[c + k];
+          const float z = xh * gm[k] + bt[k];
           const float sg = sigmoid_f(z);
           dz *= sg * (1.f + z * (1.f - sg));
         }
-        o[k] = (bf16)(rstd * (dz * gamma[c + k] - s1 - xh * s2));
+        o[k] = (bf16)(rstd * (dz * gm[k] - s1 - xh * s2));
       }
       // dx_acc / dx2_acc: the gradient x / x2 already received from their other consumers (residual / skip joins) -- added
       // here instead of in a separate launch.  They may alias dx / dx2 (each element is read and written by one thread).
@@ -562,6 +569,7 @@ static int groupnorm_bwd_impl(const void* x, const void* x2, const void* dy, con
   ALDM_CHECK_ARG(x && (dy || (dy_ws && dy_splits >= 1)) && dx && gamma && beta && B > 0 && HW > 0, "groupnorm_bwd: bad args");
   const int C = C1 + C2;
   ALDM_CHECK_ARG(C % groups == 0 && (C / groups) % 4 == 0 && C1 % 4 == 0 && (C2 == 0 || x2), "groupnorm_bwd: bad channels");
+  ALDM_CHECK_ARG(C / groups <= GNB_MAXCG, "groupnorm_bwd: at most %d channels per group", GNB_MAXCG);
   const long long nquads = (long long)HW * (C / groups / 4);
   const AldmDiv dq = aldm_make_div((unsigned)(C / groups / 4));
   ALDM_CHECK_ARG(nquads <= 32 * GN_THREADS, "groupnorm_bwd: strip of %lld quads exceeds the register-resident limit", nquads);
