@@ -55,6 +55,14 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, long long n, flo
   if (i < n) y[i] = (bf16)(x[i] * mul);
 }
 
+// guidance + DDIM update of one element, every fused multiply-add spelled out: the scalar and the vectorised kernels below then
+// round identically whatever the compiler would have contracted (tests compare them bit for bit)
+__device__ __forceinline__ float ddim_update(float eu, float et, float xv, int cfg, float g, float sa, float sb, float sap, float sbp) {
+  const float e = cfg ? fmaf(g, et - eu, eu) : eu;
+  const float x0 = fmaf(-sb, e, xv) / sa;
+  return fmaf(sap, x0, sbp * e);
+}
+
 __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, float* __restrict__ x, int B, long long n, int cfg,
                                      float g, const float* __restrict__ coef, const int* __restrict__ step_idx,
                                      bf16* __restrict__ x_in) {
@@ -63,16 +71,8 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, float* __res
   if (idx >= total) return;
   const float* cf = coef + 4 * step_idx[0];
   const float sa = cf[0], sb = cf[1], sap = cf[2], sbp = cf[3];
-  float e;
-  if (cfg) {
-    const float eu = eps[idx], et = eps[total + idx];
-    e = eu + g * (et - eu);
-  } else {
-    e = eps[idx];
-  }
-  const float xv = x[idx];
-  const float x0 = (xv - sb * e) / sa;
-  const float xn = sap * x0 + sbp * e;
+  const float eu = eps[idx], et = cfg ? eps[total + idx] : eu;
+  const float xn = ddim_update(eu, et, x[idx], cfg, g, sa, sb, sap, sbp);
   x[idx] = xn;
   if (x_in) {
     x_in[idx] = (bf16)xn;
@@ -84,37 +84,45 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, float* __res
 // (as cfg_ddim_step_kernel), the NEXT step's row of the precomputed time-embedding table gathered into `rowbias`, and the
 // device-side step counter advanced.  Every workgroup reads the counter when it starts; the one that finishes LAST (an
 // agent-scope ticket) writes the new value, so no workgroup can see the counter move under it -- three launches become one.
+// VEC elements per thread (4 when B * n % 4 == 0): a quarter of the workgroups means a quarter of the same-address ticket atomics,
+// which were most of this launch's 8.4 us (500 workgroups at one thread per element).
+template <int VEC>
 __global__ __launch_bounds__(256) void ddim_step_fused_kernel(const float* __restrict__ eps, float* __restrict__ x, int B, long long n, int cfg,
                                                               float g, const float* __restrict__ coef, int* __restrict__ step_idx,
                                                               bf16* __restrict__ x_in, const float* __restrict__ table, long long row_elems,
                                                               float* __restrict__ rowbias, const float* __restrict__ timesteps, int n_steps,
                                                               float* __restrict__ t_out, unsigned* __restrict__ ticket) {
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  typedef bf16 bvec __attribute__((ext_vector_type(VEC)));
   const int cur = step_idx[0];
   int nxt = cur + 1;
   if (nxt >= n_steps) nxt = 0;                                // wrap: a replayed graph may run past the schedule (benchmarks)
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long idx = tix * VEC;
   const long long total = (long long)B * n;
   if (idx < total) {
+    // (the operands do not depend on the counter: requested before the coefficient row, which does)
+    fvec eu = *reinterpret_cast<const fvec*>(eps + idx), et = eu;
+    if (cfg) et = *reinterpret_cast<const fvec*>(eps + total + idx);
+    const fvec xv = *reinterpret_cast<const fvec*>(x + idx);
     const float* cf = coef + 4 * cur;
     const float sa = cf[0], sb = cf[1], sap = cf[2], sbp = cf[3];
-    float e;
-    if (cfg) {
-      const float eu = eps[idx], et = eps[total + idx];
-      e = eu + g * (et - eu);
-    } else {
-      e = eps[idx];
+    fvec xn;
+    bvec xb;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float r = ddim_update(eu[k], et[k], xv[k], cfg, g, sa, sb, sap, sbp);
+      xn[k] = r;
+      xb[k] = (bf16)r;
     }
-    const float xv = x[idx];
-    const float x0 = (xv - sb * e) / sa;
-    const float xn = sap * x0 + sbp * e;
-    x[idx] = xn;
+    *reinterpret_cast<fvec*>(x + idx) = xn;
     if (x_in) {
-      x_in[idx] = (bf16)xn;
-      if (cfg) x_in[total + idx] = (bf16)xn;
+      *reinterpret_cast<bvec*>(x_in + idx) = xb;
+      if (cfg) *reinterpret_cast<bvec*>(x_in + total + idx) = xb;
     }
   }
-  if (table && idx * 4 < row_elems)
-    *reinterpret_cast<f32x4*>(rowbias + idx * 4) = *reinterpret_cast<const f32x4*>(table + (long long)nxt * row_elems + idx * 4);
+  if (table && tix * 4 < row_elems)
+    *reinterpret_cast<f32x4*>(rowbias + tix * 4) = *reinterpret_cast<const f32x4*>(table + (long long)nxt * row_elems + tix * 4);
   __syncthreads();                                            // every thread of this workgroup has read the counter
   if (threadIdx.x == 0) {
     const unsigned done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -247,9 +255,16 @@ extern "C" int aldm_ddim_step_fused(const float* eps, float* x, int B, long long
                                     const float* timesteps, int n_steps, float* t_out, unsigned* ticket, void* stream) {
   ALDM_CHECK_ARG(eps && x && coef && step_idx && timesteps && t_out && ticket && B > 0 && n_per_sample > 0 && n_steps > 0, "ddim_step_fused: bad args");
   ALDM_CHECK_ARG(!table || (rowbias && row_elems > 0 && row_elems % 4 == 0), "ddim_step_fused: table needs rowbias and row_elems %% 4 == 0");
-  const long long work = (long long)B * n_per_sample > row_elems / 4 ? (long long)B * n_per_sample : row_elems / 4;
-  hipLaunchKernelGGL(ddim_step_fused_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg,
-                     guidance, coef, step_idx, (bf16*)x_in_bf16, table, table ? row_elems : 0, rowbias, timesteps, n_steps, t_out, ticket);
+  const long long total = (long long)B * n_per_sample;
+  const bool v4 = total % 4 == 0;                       // (torch allocations are 16-byte aligned; CFG's second half starts at `total`)
+  const long long items = v4 ? total / 4 : total;
+  const long long work = items > row_elems / 4 ? items : row_elems / 4;
+  if (v4)
+    hipLaunchKernelGGL(ddim_step_fused_kernel<4>, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg,
+                       guidance, coef, step_idx, (bf16*)x_in_bf16, table, table ? row_elems : 0, rowbias, timesteps, n_steps, t_out, ticket);
+  else
+    hipLaunchKernelGGL(ddim_step_fused_kernel<1>, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, eps, x, B, n_per_sample, cfg,
+                       guidance, coef, step_idx, (bf16*)x_in_bf16, table, table ? row_elems : 0, rowbias, timesteps, n_steps, t_out, ticket);
   return aldm_launch_status("ddim_step_fused");
 }
 
