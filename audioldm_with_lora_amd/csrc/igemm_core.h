@@ -1267,10 +1267,17 @@ static __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmDev
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = (((v[q] + a0[q]) + a1[q]) + a2[q]) + a3[q];
     }
-    for (; s < p.splits; ++s) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + s * sstride);
+    if (s < p.splits) {                        // 1 .. 3 partials left: requested together, added in split order
+      const int rem = p.splits - s;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(w0 + s * sstride);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(w0 + (s + (rem > 1 ? 1 : 0)) * sstride);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(w0 + (s + (rem > 2 ? 2 : 0)) * sstride);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] += a[q];
+      for (int q = 0; q < 4; ++q) {
+        v[q] += a0[q];
+        if (rem > 1) v[q] += a1[q];
+        if (rem > 2) v[q] += a2[q];
+      }
     }
     add_bias4(p, m, n, v);
     finish_store4(p, m, n, p.N, v);

@@ -315,16 +315,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
   const int nch = C >> 3;
   const bf16* xr = x + (long long)(live ? row : 0) * C;
   bf16x8 v[LN_MAXC];
-  float s = 0.f;
+  f32x4 g0[LN_MAXC], g1[LN_MAXC], b0[LN_MAXC], b1[LN_MAXC];   // gamma / beta requested WITH the row (they were a load -> wait -> store
+  float s = 0.f;                                              // chain behind the statistics: one more L2 round trip per launch)
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
     const int ch = lane + LPR * i;
     if (ch < nch) {
       v[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+      g0[i] = *reinterpret_cast<const f32x4*>(gamma + ch * 8); g1[i] = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+      b0[i] = *reinterpret_cast<const f32x4*>(beta + ch * 8); b1[i] = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+    if (lane + LPR * i < nch) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += (float)v[i][k];
     }
-  }
   const float mean = row_sum<LPR>(s) / (float)C;
   float ss = 0.f;
 #pragma unroll
@@ -343,12 +350,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
     const int ch = lane + LPR * i;
     if (ch < nch) {
       bf16x8 o;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        o[k] = (bf16)(((float)v[i][k] - mean) * rstd * g0[k] + b0[k]);
-        o[4 + k] = (bf16)(((float)v[i][4 + k] - mean) * rstd * g1[k] + b1[k]);
+        o[k] = (bf16)(((float)v[i][k] - mean) * rstd * g0[i][k] + b0[i][k]);
+        o[4 + k] = (bf16)(((float)v[i][4 + k] - mean) * rstd * g1[i][k] + b1[i][k]);
       }
       *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
     }

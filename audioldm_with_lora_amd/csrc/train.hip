@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
   const int nch = C >> 3;
   const bf16* xr = x + (long long)(live ? row : 0) * C;
   const bf16* dr = dy + (long long)(live ? row : 0) * C;
-  bf16x8 v[LN_MAXC], d[LN_MAXC];
+  bf16x8 v[LN_MAXC], d[LN_MAXC], acc[LN_MAXC];
   float gm[LN_MAXC][8];
   float s = 0.f;
 #pragma unroll
@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     if (ch < nch) {
       v[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
       d[i] = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
+      // (the gradient the residual stream already holds: requested with the row, not as a load -> wait -> store tail)
+      if (dx_acc) acc[i] = *reinterpret_cast<const bf16x8*>(dx_acc + (long long)(live ? row : 0) * C + ch * 8);
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { gm[i][k] = g0[k]; gm[i][4 + k] = g1[k]; }
@@ -236,10 +238,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         const float xh = ((float)v[i][k] - mean) * rstd;
         r[k] = (bf16)(rstd * ((float)d[i][k] * gm[i][k] - s1 - xh * s2));
       }
-      if (dx_acc) {                            // the residual stream's gradient from its other consumers (may alias dx)
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dx_acc + (long long)row * C + ch * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = (bf16)((float)r[k] + (float)a[k]);
+      if (dx_acc) {                            // the residual stream's gradient from its other consumers (may alias dx: each element
+#pragma unroll                                 //  is read and written by one thread)
+        for (int k = 0; k < 8; ++k) r[k] = (bf16)((float)r[k] + (float)acc[i][k]);
       }
       *reinterpret_cast<bf16x8*>(o + ch * 8) = r;
     }
@@ -264,6 +265,8 @@ __global__ void geglu_fwd_kernel(const bf16* __restrict__ h, long long M, int I,
 
 __global__ void geglu_bwd_kernel(const bf16* __restrict__ h, const bf16* __restrict__ dout, long long M, int I,
                                  bf16* __restrict__ dh) {
+  // 4 outputs per thread: the kernel is VALU-bound (erf + exp per element), and 8 per thread (16-byte accesses) measured 9.6 us
+  // against 9.0 at M = 8192 -- fewer waves to overlap the transcendental chains
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = I >> 2;
   if (idx >= M * q) return;
