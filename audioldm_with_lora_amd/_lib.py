@@ -71,6 +71,7 @@ class PgemmArgs(C.Structure):
         ("max_ranges", C.c_int),
         ("waves", C.c_int),
         ("lora_t_out", C.c_void_p),
+        ("vt_dual", C.c_int),
     ]
 
 

@@ -42,6 +42,7 @@ struct PgArgs {
   const bf16* res; bf16* out; bf16* vt; float* rowstat; bf16* lora_t;
   int Rp, ln_np, out_ld;
   int vt_col0, vt_ld, OHW, vt_vec;        // vt_vec: tokens per V^T store (8, 4 or 1)
+  int dual;                               // EPI_VT: tiles at / beyond vt_col0 are ALSO stored row-major
   long long vt_bs;
   FastDiv fd_ohw;
   float ln_eps;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
     p.lora_a = ps->lora_a; p.lora_b = ps->lora_b; p.bias = ps->bias; p.ln_s = ps->ln_s; p.ln_sa = ps->ln_sa; p.ln_ca = ps->ln_ca;
     p.ln_parts = ps->ln_parts; p.res = ps->res; p.out = ps->out; p.vt = ps->vt; p.rowstat = ps->rowstat; p.lora_t = ps->lora_t;
     p.Rp = ps->Rp; p.ln_np = ps->ln_np; p.out_ld = ps->out_ld; p.vt_col0 = ps->vt_col0; p.vt_ld = ps->vt_ld; p.OHW = ps->OHW;
-    p.vt_vec = ps->vt_vec; p.vt_bs = ps->vt_bs; p.fd_ohw.mul = ps->fd_ohw.mul; p.fd_ohw.shift = ps->fd_ohw.shift;
+    p.vt_vec = ps->vt_vec; p.vt_bs = ps->vt_bs; p.fd_ohw.mul = ps->fd_ohw.mul; p.fd_ohw.shift = ps->fd_ohw.shift; p.dual = ps->dual;
     p.ln_eps = ps->ln_eps; p.diag = ps->diag;
   }
   PG_STAMP(0)
@@ -356,25 +357,17 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
     const int n_t = n_wg0 + t * NT;
     const bool vt_tile = EPI == EPI_VT && n_t >= p.vt_col0;
 
+    // (dual: the trainer's q | k | v and out-projection dX launches store every tile BOTH ways -- row-major for the next GEMM,
+    //  token-major for the flash kernels -- by running the tile's MFMAs in both operand orders; the matrix pipe has the room)
+    const bool do_std = !vt_tile || p.dual;
     f32x4 acc[MI][NJ];
+    auto acc_zero = [&]() {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (!vt_tile) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 wf[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          wf[j] = *reinterpret_cast<const bf16x8*>(Ws + rb_sw[j] + (((ks & 3) * 64) ^ vq_sw[j]) + (ks >> 2) * 256);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i][ks], acc[i][j], 0, 0, 0);
-      }
-    } else if constexpr (EPI == EPI_VT) {
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mfma_vt = [&]() {
       // V^T tile: un-swapped operand order, lane (c, q) owns rows 4 MI q .. 4 MI q + 4 MI - 1 of column 16 j + c
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -387,6 +380,22 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
 #pragma unroll
           for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i][ks], wf[j], acc[i][j], 0, 0, 0);
       }
+    };
+    acc_zero();
+    if (do_std) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          wf[j] = *reinterpret_cast<const bf16x8*>(Ws + rb_sw[j] + (((ks & 3) * 64) ^ vq_sw[j]) + (ks >> 2) * 256);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i][ks], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (EPI == EPI_VT) {
+      mfma_vt();
     }
 #ifdef PG_VERIFY   // race hunt (tools/_dbg_qkv.py): after the first barrier, is every DMA'd operand really in LDS?  counts mismatches
     if (t == 0 && p.diag) {
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
 #endif
     if (t == 2) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[MI - 1][NJ - 1][3])); PG_STAMP(44) }
     if (t == 0) stats_and_t();
-    if (!vt_tile) {
+    if (do_std) {
       if constexpr (RT > 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -490,7 +499,12 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
           }
         }
       }
-    } else if constexpr (EPI == EPI_VT) {
+    }
+    if constexpr (EPI == EPI_VT) if (vt_tile) {
+      if (do_std) {                                           // dual: the same tile again, un-swapped
+        acc_zero();
+        mfma_vt();
+      }
       if constexpr (RT > 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -712,8 +726,9 @@ extern "C" int aldm_pgemm(const aldm_pgemm_t* g0, void* stream) {
   ALDM_CHECK_ARG(!(g->geglu && (g->vt || g->res || g->rowstat_out || g->Rp)), "pgemm: GEGLU launches take no V^T / residual / statistics / LoRA");
   ALDM_CHECK_ARG(!g->geglu || nt == 64, "pgemm: GEGLU needs nt = 64");
   ALDM_CHECK_ARG(!(g->vt && (g->res || g->rowstat_out)), "pgemm: V^T launches take no residual / statistics");
-  ALDM_CHECK_ARG(!g->vt || (g->vt_col0 > 0 && g->vt_col0 % nt == 0 && g->OHW > 0 && g->M % g->OHW == 0 && g->vt_ld >= g->OHW),
-                 "pgemm: vt_col0 %d must be a positive multiple of nt %d, M a multiple of OHW", g->vt_col0, nt);
+  ALDM_CHECK_ARG(!g->vt || ((g->vt_col0 > 0 || g->vt_dual) && g->vt_col0 >= 0 && g->vt_col0 % nt == 0 && g->OHW > 0 && g->M % g->OHW == 0 && g->vt_ld >= g->OHW),
+                 "pgemm: vt_col0 %d must be a positive multiple of nt %d (0 with vt_dual), M a multiple of OHW", g->vt_col0, nt);
+  ALDM_CHECK_ARG(!g->vt_dual || g->vt, "pgemm: vt_dual without vt");
   ALDM_CHECK_ARG(g->out_ld % 8 == 0 && ((uintptr_t)g->out & 15) == 0, "pgemm: out rows must be 16-byte aligned");
   ALDM_CHECK_ARG(!g->res || ((unsigned long long)g->M * g->out_ld * 2 < 0x80000000ull && ((uintptr_t)g->res & 15) == 0), "pgemm: residual too large / misaligned");
 
@@ -727,6 +742,7 @@ extern "C" int aldm_pgemm(const aldm_pgemm_t* g0, void* stream) {
   a.Rp = g->Rp; a.ln_np = g->ln_nparts; a.out_ld = g->out_ld;
   a.vt_col0 = g->vt ? g->vt_col0 : 0x7fffffff; a.vt_ld = g->vt_ld; a.OHW = g->OHW > 0 ? g->OHW : g->M; a.vt_bs = g->vt_batch_stride;
   a.vt_vec = 1;
+  a.dual = g->vt_dual ? 1 : 0;
   if (g->vt) {
     const bool al8 = a.OHW % 8 == 0 && g->vt_ld % 8 == 0 && g->vt_batch_stride % 8 == 0 && ((uintptr_t)g->vt & 15) == 0;
     const bool al4 = a.OHW % 4 == 0 && g->vt_ld % 4 == 0 && g->vt_batch_stride % 4 == 0 && ((uintptr_t)g->vt & 7) == 0;

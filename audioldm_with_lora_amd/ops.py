@@ -498,15 +498,15 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             and pw.N % 64 == 0 and out.dtype == torch.bfloat16 and out_pix_stride == 1 and out_pix_offset == 0
             and out_batch_stride == OH * OW * out_ld and out_ld % 8 == 0 and rowbias is None and out_act == ACT_NONE
             and post_act == ACT_NONE and res2 is None and out2 is None and alpha == 1.0 and (lora_t_out is None or pw.Rp)
-            and splits in (None, 1) and gn is None and not vt_dual
+            and splits in (None, 1) and gn is None and (not vt_dual or vt is not None)
             and not (qstats and OH * OW >= QSTATS_MIN_HW)
             and (not pw.Rp or getattr(pw, "ranks_used", 99) <= 32)
             and (pw.ln_s is None or (ln_parts is not None and ln_parts.shape[1] <= 16))
             and not (pw.geglu and (res is not None or vt is not None or pw.Rp or rowstats))
-            and not (vt is not None and (res is not None or rowstats or vt_col0 % 32 or vt_col0 <= 0))
+            and not (vt is not None and (res is not None or rowstats or vt_col0 % 32 or (vt_col0 <= 0 and not vt_dual) or vt_col0 < 0))
             and (res is None or (res.is_contiguous() and res.numel() == B * OH * OW * out_ld))
-            and PGEMM_CFG.get(_pgemm_key(B * OH * OW, pw, C1, res, vt, rowstats, lora_t_out is not None)) != PGEMM_USE_IGEMM):
-        return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts, lora_t_out)
+            and PGEMM_CFG.get(_pgemm_key(B * OH * OW, pw, C1, res, vt, rowstats, lora_t_out is not None, vt_dual)) != PGEMM_USE_IGEMM):
+        return _pgemm(x, pw, out, out_ld, B * OH * OW, C1, OH * OW, res, vt, vt_col0, vt_ld, vt_batch_stride, rowstats, ln_parts, lora_t_out, vt_dual)
     a = IgemmArgs()
     if x3 is not None:
         for t in (x3, x4):
@@ -687,13 +687,13 @@ if os.path.exists(PGEMM_TUNED_PATH) and os.environ.get("ALDM_NO_TUNED") != "1":
 PGEMM_USE_IGEMM = (0, 0, 0, 0)                               # table entry: this GEMM measured faster on aldm_igemm, keep it there
 
 
-def _pgemm_key(M, pw, K, res, vt, rowstats=False, lora_t=False):
+def _pgemm_key(M, pw, K, res, vt, rowstats=False, lora_t=False, dual=False):
     kind = (("g" if pw.geglu else "") + ("v" if vt is not None else "") + ("r" if res is not None else "") + (f"l{pw.Rp}" if pw.Rp else "")
-            + ("s" if rowstats else "") + ("t" if lora_t else ""))
+            + ("s" if rowstats else "") + ("t" if lora_t else "") + ("d" if dual else ""))
     return (M, pw.N, K, kind)
 
 
-def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowstats, ln_parts, lora_t_out=None):
+def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowstats, ln_parts, lora_t_out=None, vt_dual=False):
     """conv()'s 1x1 / short-K case on aldm_pgemm: same operands, same results (to rounding), a kernel built for it."""
     lib = _lib.load()
     a = _lib.PgemmArgs()
@@ -717,7 +717,8 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
     a.out, a.out_ld = out.data_ptr(), out_ld
     if vt is not None:
         a.vt, a.vt_col0, a.vt_ld, a.vt_batch_stride, a.OHW = vt.data_ptr(), vt_col0, vt_ld, vt_bs, OHW
-    cfg = PGEMM_CFG.get(_pgemm_key(M, pw, K, res, vt, rowstats, lora_t_out is not None))
+        a.vt_dual = 1 if vt_dual else 0
+    cfg = PGEMM_CFG.get(_pgemm_key(M, pw, K, res, vt, rowstats, lora_t_out is not None, vt_dual))
     if cfg is not None and rowstats and pw.N // (cfg[1] * cfg[2]) > 16:
         cfg = None                                           # (consumers take at most 16 partial pairs per row)
     if cfg is not None:
@@ -730,10 +731,10 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
     if rowstats:
         stats = torch.empty(M, pw.N // (a.nt * a.tiles_per_range), 2, dtype=torch.float32, device=x.device)
         a.rowstat_out = stats.data_ptr()
-    ncols = pw.N // 2 if pw.geglu else (vt_col0 if vt is not None else pw.N)
+    ncols = pw.N // 2 if pw.geglu else (vt_col0 if (vt is not None and not vt_dual) else pw.N)
     flops = 2.0 * M * pw.N * K + (2.0 * M * pw.Rp * (K + pw.N) if pw.Rp else 0.0)
     nbytes = 2.0 * (M * K + pw.N * K + M * ncols)
-    label = (f"pgemm_{16 * a.mi * a.waves}x{a.nt}x{a.tiles_per_range}w{a.waves}_r{pw.Rp}{'_vt' if vt is not None else ''}"
+    label = (f"pgemm_{16 * a.mi * a.waves}x{a.nt}x{a.tiles_per_range}w{a.waves}_r{pw.Rp}{'_vt' if vt is not None else ''}{'d' if vt_dual else ''}"
              f"|M{M} N{pw.N} K{K}{' geglu' if pw.geglu else ''}")
     if hasattr(out, "qstats"):
         del out.qstats                                       # (see conv(): never leave a stale GroupNorm table on a rewritten buffer)

@@ -163,6 +163,7 @@ typedef struct {
   int max_ranges;           /* plan only: at most this many column ranges per row (= partials per row of rowstat_out); 0 = any */
   int waves;
   void* lora_t_out;         /* optional [M][Rp] bf16 copy of T = x A^T (the LoRA trainer saves it for dB = s dY^T T), as aldm_igemm_t */
+  int vt_dual;              /* columns >= vt_col0 (which may then be 0) are stored token-major in vt AND row-major in out (as aldm_igemm_t) */
 } aldm_pgemm_t;
 
 int aldm_pgemm_supported(int K);

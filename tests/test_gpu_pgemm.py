@@ -169,6 +169,35 @@ def test_qkv_layernorm_folded_lora_vt(ops, labels, B, N, C, r, nparts):
     assert all(l[0].startswith("pgemm_") for l in labels), [l[0] for l in labels]
 
 
+@pytest.mark.parametrize("B,N,C,Nout,r", [(2, 1024, 256, 768, 8), (2, 256, 384, 1152, 4), (3, 64, 640, 640, 8), (2, 60, 256, 256, 16)])
+def test_dual_store_row_major_and_token_major(ops, labels, B, N, C, Nout, r):
+    """the trainer's q | k | v forward and out-projection dX launches (training.t_lora_linear): every column stored row-major AND
+    token-major, LoRA fused, T = x A^T handed out (vt_dual, as aldm_igemm's): both layouts hold the same bf16 values."""
+    g = torch.Generator().manual_seed(9)
+    M = B * N
+    x = bf(torch.randn(M, C, generator=g))
+    w = bf(torch.randn(Nout, C, generator=g) / math.sqrt(C))
+    b = torch.randn(Nout, generator=g)
+    A = bf(torch.randn(r, C, generator=g) / r)
+    Bm = bf(torch.randn(Nout, r, generator=g) * 0.05)
+    want = x @ w.t() + b + 2.0 * (x @ A.t()) @ Bm.t()
+    pw = ops.pack_linear(w.to(DEV), b.to(DEV))
+    ops.attach_lora(pw, [(0, Nout, A.to(DEV), Bm.to(DEV), 2.0)])
+    npad = (N + 7) // 8 * 8
+    for cfg in shapes_for(C, Nout, vt_col0=Nout, rp=pw.Rp):
+        ops.PGEMM_CFG[(M, Nout, C, f"vl{pw.Rp}td")] = cfg
+        yT = torch.zeros(B, Nout, npad, dtype=torch.bfloat16, device=DEV)
+        T = torch.empty(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
+        y = ops.conv(dv(x).view(B, 1, N, C), pw, lora_t_out=T, splits=1, vt=yT, vt_col0=0, vt_ld=npad, vt_batch_stride=Nout * npad,
+                     vt_dual=True).view(M, Nout)
+        close(y, want, rtol=2e-2)
+        assert torch.equal(yT[:, :, :N].permute(0, 2, 1).reshape(M, Nout), y), cfg       # the same values, two layouts
+        assert not yT[:, :, N:].any()
+        close(T[:, :r], x @ A.t(), rtol=2e-2)
+    ops.PGEMM_CFG.clear()
+    assert labels and all(l[0].startswith("pgemm_") and "_vtd" in l[0] for l in labels), [l[0] for l in labels]
+
+
 @pytest.mark.parametrize("M,C,nparts", [(1000, 256, 4), (2016, 384, 3), (130, 640, 5)])
 def test_geglu_layernorm_folded(ops, labels, M, C, nparts):
     g = torch.Generator().manual_seed(4)

@@ -39,6 +39,18 @@ def make_case(kind, M, N, K, B, nbuf=3):
         res = [torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) for _ in range(nbuf)]
         T = torch.empty(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
         return f"rl{pw.Rp}t", lambda i: ops.linear(xs[i], pw, res=res[i], lora_t_out=T)
+    if kind == "dual":                                       # the trainer's q | k | v forward (N = 3C, rank 8 each) / out-projection dX (N = C)
+        pw = ops.pack_linear(w, b)
+        nl = 3 if N > K else 1
+        ops.attach_lora(pw, [(j * (N // nl), N // nl, (torch.randn(8, K, generator=g) / 8).to(DEV), (torch.randn(N // nl, 8, generator=g) * 0.05).to(DEV), 1.0)
+                             for j in range(nl)])
+        pw.ranks_used = 8 * nl
+        n = M // B
+        npad = (n + 7) // 8 * 8
+        yTs = [torch.zeros(B, N, npad, dtype=torch.bfloat16, device=DEV) for _ in range(nbuf)]
+        T = torch.empty(M, pw.Rp, dtype=torch.bfloat16, device=DEV)
+        return f"vl{pw.Rp}td", lambda i: ops.conv(xs[i].view(B, 1, n, K), pw, lora_t_out=T, splits=1, vt=yTs[i], vt_col0=0, vt_ld=npad,
+                                                  vt_batch_stride=N * npad, vt_dual=True)
     if kind == "out":
         pw = ops.pack_linear(w, b)
         ops.attach_lora(pw, [lora(0, N)])
@@ -67,7 +79,7 @@ def configs(kind, M, N, K):
                     continue
                 nti = N // nt
                 res = kind in ("out", "out_t")
-                rp = 32 if kind in ("out", "qkv", "out_t") else 0
+                rp = 32 if kind in ("out", "qkv", "out_t", "dual") else 0
                 bm = 16 * mi * nw
                 stage = nt * K * 2 + (bm * nt * 2 if res else 0)
                 for t in range(1, nti + 1):
@@ -118,7 +130,7 @@ def main():
     jobs = [(B, C, n, kinds) for B in a.batch for C, n, kinds in
             ((256, 1000, None), (384, 252, None), (640, 64, None))]
     if a.train:                                              # proj_in / its dX / ff2's dX (plain), to_out.0 forward (LoRA + residual + T copy)
-        jobs += [(8, C, n, (("plain", C), ("plain", 4 * C), ("out_t", C))) for C, n in ((256, 1024), (384, 256), (640, 64))]
+        jobs += [(8, C, n, (("plain", C), ("plain", 4 * C), ("out_t", C), ("dual", 3 * C), ("dual", C))) for C, n in ((256, 1024), (384, 256), (640, 64))]
     for B, C, n, kinds in jobs:
         if True:
             M = B * n
