@@ -218,24 +218,6 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   }
   if (second) splits = 0;
   int sp = 0;
-  if constexpr (QPT <= 2) {
-    // short strips (the 64- and 252-token levels, 2 .. 12 partials): up to eight partials requested together -- with four per
-    // trip a 6-way split is two dependent L2 round trips, a third of this launch
-    for (; sp < splits; sp += 8) {
-      const int rem = splits - sp;
-#pragma unroll
-      for (int i = 0; i < QPT; ++i) {
-        if (tid + i * GN_THREADS < nquads) {
-          const float* w0 = ws + off[i] + sp * sstride;
-          f32x4 a[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(w0 + (u < rem ? u : 0) * sstride);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) if (u < rem) v[i] += a[u];      // in split order
-        }
-      }
-    }
-  }
   for (; sp + 4 <= splits; sp += 4) {
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
