@@ -58,17 +58,20 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
   // 4-byte loads with a wait each, in both sweeps
   if (tid < Cg) { sgm[tid] = gamma[c0 + tid]; sbt[tid] = beta[c0 + tid]; }
 
-  bf16x4 v[QPT], d[QPT];
+  bf16x4 v[QPT], d[QPT], pa[QPT];                       // pa: the gradient x / x2 already hold (dx_acc / dx2_acc), requested with the strip
   float s = 0.f, dummy = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * NT;
     bf16x4 t = {0, 0, 0, 0}, u = {0, 0, 0, 0};
+    pa[i] = bf16x4{0, 0, 0, 0};
     if (q < nquads) {
       const int pix = aldm_div(q, dqpp), j = q - pix * qpp;
       const int c = c0 + 4 * j;
       t = (c < C1) ? *reinterpret_cast<const bf16x4*>(x + ((long long)b * HW + pix) * C1 + c)
                    : *reinterpret_cast<const bf16x4*>(x2 + ((long long)b * HW + pix) * C2 + (c - C1));
+      if (c < C1) { if (dx_acc) pa[i] = *reinterpret_cast<const bf16x4*>(dx_acc + ((long long)b * HW + pix) * C1 + c); }
+      else if (dx2 && dx2_acc) pa[i] = *reinterpret_cast<const bf16x4*>(dx2_acc + ((long long)b * HW + pix) * C2 + (c - C1));
       const long long doff = ((long long)b * HW + pix) * C + c;
       if (dy_ws) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -105,11 +108,15 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
   block_sum2<NT>(ss, dummy, red, tid);
   const float rstd = rsqrtf(ss / n + eps);
 
-  // gdz = dz * gamma kept in fp32 registers would double the footprint: recompute it in the second sweep
+  // gd = dz * gamma: short strips keep it in fp32 registers for the second sweep (the SiLU derivative costs an exp and a
+  // reciprocal per element); for the long ones that would double the footprint, so they recompute it
+  constexpr bool KEEP = QPT <= 8;
+  f32x4 gdk[KEEP ? QPT : 1];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * NT;
+    if constexpr (KEEP) gdk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q < nquads) {
       const int j = q - aldm_div(q, dqpp) * qpp;
       const f32x4 gm = *reinterpret_cast<const f32x4*>(sgm + 4 * j), bt = *reinterpret_cast<const f32x4*>(sbt + 4 * j);
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
           dz *= sg * (1.f + z * (1.f - sg));
         }
         const float gd = dz * gm[k];
+        if constexpr (KEEP) gdk[i][k] = gd;
         s1 += gd;
         s2 += gd * xh;
       }
@@ -142,23 +150,29 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = ((float)v[i][k] - mean) * rstd;
-        float dz = (float)d[i][k];
-        if (act == ALDM_ACT_SILU) {
-          const float z = xh * gm[k] + bt[k];
-          const float sg = sigmoid_f(z);
-          dz *= sg * (1.f + z * (1.f - sg));
+        float gd;
+        if constexpr (KEEP) {
+          gd = gdk[i][k];
+        } else {
+          float dz = (float)d[i][k];
+          if (act == ALDM_ACT_SILU) {
+            const float z = xh * gm[k] + bt[k];
+            const float sg = sigmoid_f(z);
+            dz *= sg * (1.f + z * (1.f - sg));
+          }
+          gd = dz * gm[k];
         }
-        o[k] = (bf16)(rstd * (dz * gm[k] - s1 - xh * s2));
+        o[k] = (bf16)(rstd * (gd - s1 - xh * s2));
       }
       // dx_acc / dx2_acc: the gradient x / x2 already received from their other consumers (residual / skip joins) -- added
       // here instead of in a separate launch.  They may alias dx / dx2 (each element is read and written by one thread).
       if (c < C1) {
         const long long off = ((long long)b * HW + pix) * C1 + c;
-        if (dx_acc) { const bf16x4 a = *reinterpret_cast<const bf16x4*>(dx_acc + off); for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
+        if (dx_acc) { for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)pa[i][k]); }
         *reinterpret_cast<bf16x4*>(dx + off) = o;
       } else if (dx2) {
         const long long off = ((long long)b * HW + pix) * C2 + (c - C1);
-        if (dx2_acc) { const bf16x4 a = *reinterpret_cast<const bf16x4*>(dx2_acc + off); for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)a[k]); }
+        if (dx2_acc) { for (int k = 0; k < 4; ++k) o[k] = (bf16)((float)o[k] + (float)pa[i][k]); }
         *reinterpret_cast<bf16x4*>(dx2 + off) = o;
       }
     }
