@@ -41,8 +41,12 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 template <int DP>
 struct AttnCfg {
   static constexpr int DK = DP / 16;                       // QK^T k-steps
-  static constexpr int DT = DP / 32 + 1;                   // 32-row d-tiles of O^T, INCLUDING the row of ones at row DP
-  static constexpr int ONES_T = DP / 32;                   // tile / accumulator register that holds l = sum p (lanes hh = 0)
+  // VL: the row sum l = sum_k p is accumulated by VALU adds instead of the row of ones.  Where DP is a multiple of 32 (d = 32, 64) the
+  // ones row needs a d-tile of its own -- 4 of the 12 MFMAs per 64-key tile at d = 32 -- and, MFMA and VALU time being additive on this
+  // chip (see the header), 32 adds (64-128 cycles) are cheaper than 4 MFMAs (128 cycles) plus their 4 fragment reads.
+  static constexpr bool VL = DP % 32 == 0;
+  static constexpr int DT = VL ? DP / 32 : DP / 32 + 1;    // 32-row d-tiles of O^T, INCLUDING (unless VL) the row of ones at row DP
+  static constexpr int ONES_T = VL ? 0 : DP / 32;          // tile / accumulator register that holds l = sum p (lanes hh = 0)
   static constexpr int ONES_I = 4 * ((DP % 32) >> 3);
   static_assert(DP % 16 == 0, "row DP must land on hh = 0, register 4 * (row / 8)");
   static constexpr int KS = DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);  // K LDS row stride (odd number of 16-B slots)
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     const int npad = DT * 32 - D;
     for (int i = tid; i < 2 * SP * npad * (VS / 8); i += T) {
       const int buf = i / (npad * (VS / 8)), rem = i - buf * npad * (VS / 8);
-      const unsigned fill = (D + rem / (VS / 8) == DP) ? 0x3F803F80u : 0u;
+      const unsigned fill = (!Cfg::VL && D + rem / (VS / 8) == DP) ? 0x3F803F80u : 0u;
       reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + D * VS)[rem] = make_uint2(fill, fill);
     }
   }
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float m_run = 0.f;                            // running maximum of the SCALED scores (log2 domain); set by the first tile
+  float l_run = 0.f;                            // VL: this lane's share of l (its 32 keys of every tile)
 
   const int ntiles = (Nk + KV - 1) / KV;
   const int niter = (ntiles + SP - 1) / SP;
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         for (int t = 0; t < DT; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) o[t][i] *= alpha;                // includes l (row DP)
+        if constexpr (Cfg::VL) l_run *= alpha;
       }
       if (PRESCALED) {
 #pragma unroll
@@ -290,13 +296,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       }
     }
     bf16x8 pf[4];
+    float lp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float e = PRESCALED ? s[sub][i] : fmaf(s[sub][i], c, -m_run);
-        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)__builtin_amdgcn_exp2f(e);
+        const float pe = __builtin_amdgcn_exp2f(e);
+        if constexpr (Cfg::VL) lp[i & 3] += pe;
+        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)pe;
       }
+    if constexpr (Cfg::VL) l_run += (lp[0] + lp[1]) + (lp[2] + lp[3]);
     // ---- O^T += V^T P^T (row DP of V^T is ones: l accumulates alongside) ----
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   if constexpr (SP > 1) {
     // ---- merge the key groups: groups 1.. leave (m, l, O^T) in LDS (the staging buffers are dead after the last barrier),
     // group 0 folds them in.  Layout [value][lane] per wave: conflict-free 4-byte accesses. ----
-    constexpr int WVALS = DT * 16 + 1;
+    constexpr int WVALS = DT * 16 + 2;                           // m, O^T, l_run (VL)
     float* xch = reinterpret_cast<float*>(smem);
     const bool idle = grp * KV >= Nk;                            // (wave-uniform) this group never saw a tile: O^T = 0, l = 0
     if (grp > 0) {
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mine[(1 + t * 16 + i) * 64 + lane] = o[t][i];
+      mine[(1 + DT * 16) * 64 + lane] = l_run;
     }
     __syncthreads();
     if (grp > 0) return;
@@ -367,12 +378,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * a0 + peer[(1 + t * 16 + i) * 64 + lane] * a1;   // l (row DP) merges like any row
+      l_run = l_run * a0 + peer[(1 + DT * 16) * 64 + lane] * a1;
     }
   }
 
   // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
   // l sits in O^T row DP: register ONES_I of tile ONES_T on the hh = 0 lanes (the hh = 1 lanes hold row DP + 4 there: zero padding)
-  const float l_half = o[Cfg::ONES_T][Cfg::ONES_I];
+  const float l_half = Cfg::VL ? l_run : o[Cfg::ONES_T][Cfg::ONES_I];   // (VL: this lane's 32 keys per tile; the other 32 sit in lane ^ 32)
   const float l_tot = l_half + __shfl_xor(l_half, 32, 64);
   const float inv = 1.0f / l_tot;
   if (lse && hh == 0 && q0 + r < N)   // log2-domain log-sum-exp of the scaled scores: p = exp2(s*c - lse)
