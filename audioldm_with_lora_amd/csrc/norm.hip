@@ -6,6 +6,7 @@
 // the VAE's group norms; LayerNorm serves BasicTransformerBlock.norm1/2/3 -- all under
 // UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546] /
 // AutoencoderKL.decode [REF script/inference/generate_audio.py:47-52].
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -644,6 +645,11 @@ extern "C" int aldm_embed_layernorm(const long long* ids, int B, int L, int C, c
   return aldm_launch_status("embed_layernorm");
 }
 
+static int gn_apply_bytes() {
+  static const int v = getenv("ALDM_GN_APPLY_BYTES") ? atoi(getenv("ALDM_GN_APPLY_BYTES")) : 32768;
+  return v;
+}
+
 extern "C" int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, int tpi, const void* x2, const float* qstat2, int bm2,
                                     int tpi2, int B, int HW, int C1, int C2, int groups, float eps, const float* gamma,
                                     const float* beta, int act, void* y, float* stat_ws, void* stream) {
@@ -658,7 +664,7 @@ extern "C" int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, i
   int lpg = 1;
   while (lpg * 2 * groups <= 256 && lpg < 64) lpg *= 2;      // lanes per group (power of two, whole groups inside one wave)
   int pxb = 16;
-  while (pxb < 256 && pxb * C * 2 < 32768) pxb *= 2;         // ~32 KB of pixels per workgroup
+  while (pxb < 256 && pxb * C * 2 < gn_apply_bytes()) pxb *= 2;   // ~32 KB of pixels per workgroup (ALDM_GN_APPLY_BYTES: tuning aid)
   GnSrc s1{(const bf16*)x, qstat, C1, bm, tpi}, s2{(const bf16*)x2, qstat2, C2, bm2, tpi2};
   // tiles per image the statistics phase walks; past ALDM_GN_FINALIZE_MIN_TILES a one-workgroup-per-image launch sums them once
   const int tiles = max(tpi > 0 ? tpi : HW / bm + 1, C2 ? (tpi2 > 0 ? tpi2 : HW / bm2 + 1) : 0);
