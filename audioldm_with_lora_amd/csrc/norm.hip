@@ -564,6 +564,122 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnSrc s1, GnSrc s2
   }
 }
 
+
+// ---- GroupNorm + SiLU + 3x3 convolution to a few channels, one launch (conv_norm_out -> SiLU -> conv_out at the UNet's exit) ----
+// The apply pass of the norm wrote 8 MB that the 128 -> 8 channel convolution then read nine times through L2 on a 64-column tile
+// with 8 live columns (9 + 14.5 us).  Here a workgroup takes RB image rows of one image: statistics from the producer's tables (as
+// groupnorm_apply), the rows plus a one-pixel halo normalised + SiLU'd ONCE on their way into LDS (padding pixels are zeros, as the
+// convolution pads the ACTIVATION), the weights (Cout x 9 C) next to them, and the nine taps as shifted LDS reads feeding
+// v_mfma_f32_16x16x32_bf16: one image row of W = 16 pixels is one M-tile, the Cout <= 16 output channels its N.
+constexpr int GC_W = 16, GC_RB = 8, GC_PIX = 272;            // 272-byte pixel stride (256 + 16): the 16 pixel lanes of a fragment read spread over all banks
+
+template <int C>
+__global__ __launch_bounds__(256) void gn_silu_conv3x3_small_kernel(GnSrc s1, int H, int groups, float eps, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const bf16* __restrict__ w, int w_ld,
+                                                                    const float* __restrict__ bias, int Cout, float* __restrict__ out, int lpg) {
+  static_assert(C == 128, "tile sizes below are for 128 input channels");
+  constexpr int CH = C / 8;                                   // 16-byte chunks per pixel
+  constexpr int WROW = 9 * C * 2 + 16;                        // weight row stride in LDS (+16: rows on different banks)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                                            // [(RB + 2) x (W + 2) pixels][GC_PIX]
+  char* Ws = smem + (GC_RB + 2) * (GC_W + 2) * GC_PIX;        // [16][WROW] (rows >= Cout are never read)
+  __shared__ float sm[64], sr[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, r0 = blockIdx.x * GC_RB;
+  const int HW = H * GC_W, Cg = C / groups;
+  {   // statistics: lpg lanes per group
+    const int g = tid / lpg, j = tid - g * lpg;
+    float a = 0.f, q2 = 0.f;
+    GnSrc none{nullptr, nullptr, 0, 1, 0};
+    if (g < groups) gn_group_sums(s1, none, b, HW, Cg, g, j, lpg, a, q2);
+    for (int o = 1; o < lpg; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
+    if (g < groups && j == 0) {
+      const float n = (float)HW * (float)Cg;
+      const float mu = a / n;
+      sm[g] = mu;
+      sr[g] = rsqrtf(fmaxf(q2 / n - mu * mu, 0.f) + eps);
+    }
+  }
+  // weights -> LDS (independent of the statistics: issued before the barrier)
+  for (int i = tid; i < Cout * (9 * C / 8); i += 256) {
+    const int o = i / (9 * C / 8), ck = i - o * (9 * C / 8);
+    *reinterpret_cast<bf16x8*>(Ws + o * WROW + ck * 16) = *reinterpret_cast<const bf16x8*>(w + (long long)o * w_ld + ck * 8);
+  }
+  // the strip's raw values: thread = one 16-byte channel chunk (tid & 15) of pixels (tid >> 4) + 16 j of the (RB + 2) x W strip
+  constexpr int NPX = (GC_RB + 2) * GC_W, PPT = NPX / 16;     // 160 pixels, 10 per thread
+  const int cu = tid & (CH - 1), c = cu * 8;
+  bf16x8 v[PPT];
+  bool inimg[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int pl = (tid >> 4) + 16 * j;
+    const int row = r0 - 1 + pl / GC_W, col = pl % GC_W;
+    inimg[j] = row >= 0 && row < H;
+    const int rr = min(max(row, 0), H - 1);
+    v[j] = *reinterpret_cast<const bf16x8*>(s1.x + ((long long)b * HW + (long long)rr * GC_W + col) * C + c);
+  }
+  // zero the two padding columns of every strip row
+  for (int i = tid; i < (GC_RB + 2) * 2 * CH; i += 256) {
+    const int rowi = i / (2 * CH), rem = i - rowi * 2 * CH;
+    const int colp = (rem / CH) ? (GC_W + 1) : 0;
+    *reinterpret_cast<uint4*>(Xs + (rowi * (GC_W + 2) + colp) * GC_PIX + (rem % CH) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();                                            // statistics ready
+  {
+    const int gA = c / Cg, gB = (c + 4) / Cg;
+    const float mA = sm[gA], rA = sr[gA], mB = sm[gB], rB = sr[gB];
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sc[k] = g0[k] * rA; sh[k] = b0[k] - mA * sc[k];
+      sc[4 + k] = g1[k] * rB; sh[4 + k] = b1[k] - mB * sc[4 + k];
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int pl = (tid >> 4) + 16 * j;
+      const int rowi = pl / GC_W, col = pl % GC_W;
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = inimg[j] ? (bf16)silu_f(fmaf((float)v[j][k], sc[k], sh[k])) : (bf16)0.f;
+      *reinterpret_cast<bf16x8*>(Xs + (rowi * (GC_W + 2) + col + 1) * GC_PIX + cu * 16) = o;
+    }
+  }
+  __syncthreads();
+  // ---- 9 taps x C / 32 k-steps; wave = 2 image rows (2 M-tiles), lane (m = lane & 15: pixel / output channel, q = lane >> 4: 8-wide k chunk)
+  const int m = lane & 15, q = lane >> 4;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;                     // strip row = image row - r0 + 1 + (dy - 1); column + 1 + (dx - 1)
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks) {
+      const bf16x8 wf = m < Cout ? *reinterpret_cast<const bf16x8*>(Ws + m * WROW + (tap * C + ks * 32 + q * 8) * 2) : zero8;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rowi = 2 * wave + t + dy;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + (rowi * (GC_W + 2) + m + dx) * GC_PIX + (ks * 32 + q * 8) * 2);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D[pixel 4 q + i][channel m]
+  if (m < Cout) {
+    const float bb = bias ? bias[m] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = r0 + 2 * wave + t;
+      if (row < H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          out[((long long)b * HW + (long long)row * GC_W + 4 * q + i) * Cout + m] = acc[t][i] + bb;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int aldm_groupnorm(const void* x, const void* x2, int B, int HW, int C1, int C2, int groups, float eps,
@@ -676,4 +792,24 @@ extern "C" int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, i
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(cdiv(HW, pxb), B), dim3(256), 0, (hipStream_t)stream, s1, s2, HW, groups, eps, gamma,
                      beta, act, (bf16*)y, pxb, lpg, aldm_make_div((unsigned)(C >> 3)), two_phase ? (const float*)stat_ws : nullptr);
   return aldm_launch_status("groupnorm_apply");
+}
+
+extern "C" int aldm_gn_silu_conv3x3_small(const void* x, const float* qstat, int bm, int tpi, int B, int H, int W, int C, int groups,
+                                          float eps, const float* gamma, const float* beta, const void* w, int w_ld, const float* bias,
+                                          int Cout, float* out, void* stream) {
+  ALDM_CHECK_ARG(x && qstat && gamma && beta && w && out, "gn_silu_conv3x3_small: null pointer");
+  ALDM_CHECK_ARG(B > 0 && H > 0 && W == GC_W && C == 128 && Cout >= 1 && Cout <= 16 && w_ld >= 9 * C && w_ld % 8 == 0,
+                 "gn_silu_conv3x3_small: built for W = 16, C = 128, Cout <= 16 (got W %d, C %d, Cout %d)", W, C, Cout);
+  ALDM_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 4 == 0, "gn_silu_conv3x3_small: bad groups");
+  ALDM_CHECK_ARG(tpi > 0 || (bm > 0 && bm <= H * W), "gn_silu_conv3x3_small: an M-tile of the producer may span at most two images");
+  int lpg = 1;
+  while (lpg * 2 * groups <= 256 && lpg < 64) lpg *= 2;
+  const int lds = (GC_RB + 2) * (GC_W + 2) * GC_PIX + 16 * (9 * 128 * 2 + 16);
+  auto kern = gn_silu_conv3x3_small_kernel<128>;
+  static unsigned long long attr_done = 0;
+  if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), lds, &attr_done, "gn_silu_conv3x3_small")) return rc;
+  GnSrc s1{(const bf16*)x, qstat, C, bm, tpi};
+  hipLaunchKernelGGL(kern, dim3(cdiv(H, GC_RB), B), dim3(256), lds, (hipStream_t)stream, s1, H, groups, eps, gamma, beta, (const bf16*)w, w_ld,
+                     bias, Cout, out, lpg);
+  return aldm_launch_status("gn_silu_conv3x3_small");
 }

@@ -795,6 +795,29 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     return y
 
 
+def gn_silu_conv_out_ok(x, pw, groups):
+    """Can conv_norm_out -> SiLU -> conv_out run as the one fused launch?  (the AudioLDM latent: width 16, 128 channels, <= 16 outputs,
+    3x3 / pad 1, GroupNorm statistics handed over by the convolution that produced x)"""
+    q = getattr(x, "qstats", None) if isinstance(x, torch.Tensor) else None
+    return (q is not None and x.dim() == 4 and x.shape[2] == 16 and x.shape[3] == 128 and x.is_contiguous() and x.dtype == torch.bfloat16
+            and pw.KH == 3 and pw.KW == 3 and pw.N <= 16 and pw.Cin == 128 and not pw.Rp and 128 % groups == 0 and (128 // groups) % 4 == 0
+            and groups <= 64 and (q.tpi > 0 or q.bm <= x.shape[1] * x.shape[2]))
+
+
+def gn_silu_conv_out(x, gamma, beta, groups, eps, pw):
+    """F.silu(F.group_norm(x)) -> 3x3 conv (pad 1) to pw.N channels, fp32 NHWC out, ONE launch (aldm_gn_silu_conv3x3_small)."""
+    _require_gpu(x)
+    B, H, W, Cc = x.shape
+    q = x.qstats
+    out = torch.empty(B, H, W, pw.N, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    n = B * H * W
+    check(_launch(f"gn_silu_conv3x3|HW{H * W} C{Cc} N{pw.N}", 2.0 * n * pw.N * 9 * Cc + 10.0 * n * Cc, 2.0 * n * Cc + 4.0 * n * pw.N,
+                  lambda: lib.aldm_gn_silu_conv3x3_small(_p(x), _p(q.table), q.bm, q.tpi, B, H, W, Cc, groups, eps, _p(gamma), _p(beta), _p(pw.w),
+                                                         pw.Kpad, _p(pw.bias), pw.N, _p(out), _stream())), "aldm_gn_silu_conv3x3_small")
+    return out
+
+
 def layernorm(x2d, gamma, beta, eps=1e-5):
     _require_gpu(x2d)
     M, Cc = x2d.shape

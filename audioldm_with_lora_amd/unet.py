@@ -547,6 +547,8 @@ class UNet2DConditionModel(nn.Module):
                 else:
                     size = (h.shape[1] * 2, h.shape[2] * 2)
                 h = ops.conv(h, blk.up, pad=(1, 1), up_size=size, defer=norm1_of(P.up[bi + 1].resnets[0]), qstats=True)
+        if ops.gn_silu_conv_out_ok(h, P.conv_out, groups):        # norm + SiLU + the 128 -> 8 channel convolution as one launch
+            return ops.gn_silu_conv_out(h, P.gn_out[0], P.gn_out[1], groups, eps, P.conv_out)
         h = ops.groupnorm(h, P.gn_out[0], P.gn_out[1], groups, eps, ACT_SILU)
         return ops.conv(h, P.conv_out, pad=(1, 1), out_f32=True)
 

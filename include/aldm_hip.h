@@ -190,6 +190,15 @@ int aldm_groupnorm_apply(const void* x, const float* qstat, int bm, int tpi, con
                          int B, int HW, int C1, int C2, int groups, float eps, const float* gamma, const float* beta, int act,
                          void* y, float* stat_ws, void* stream);
 
+/* conv_norm_out -> SiLU -> conv_out of UNet2DConditionModel.forward [REF script/train/train_audioldm_lora.py:539-546] as ONE launch:
+   GroupNorm (statistics from the producing aldm_igemm's qstat_out table, as aldm_groupnorm_apply) + SiLU applied to each image-row
+   strip once on its way into LDS, then the 3x3 / pad 1 convolution to Cout <= 16 channels from there.  x bf16 [B][H][W][C] with
+   W = 16 and C = 128 (the AudioLDM latent: 64 mel bins / 4); w bf16 [Cout][w_ld] in (kh, kw, c) order as ops.pack_conv leaves it;
+   out fp32 [B][H][W][Cout]. */
+int aldm_gn_silu_conv3x3_small(const void* x, const float* qstat, int bm, int tpi, int B, int H, int W, int C, int groups, float eps,
+                               const float* gamma, const float* beta, const void* w, int w_ld, const float* bias, int Cout, float* out,
+                               void* stream);
+
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3). */
 int aldm_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps, void* y,
                    void* stream);

@@ -346,6 +346,31 @@ def test_groupnorm_apply_from_conv_statistics(ops, B, H, W, C1, C2, groups, tile
     close(to_nchw(got), to_nchw(ref).float(), rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("B,H,tile", [(2, 250, 0), (1, 128, 0), (3, 131, 0), (2, 250, 7), (2, 133, 2), (8, 250, 6)])
+def test_gn_silu_conv_out_one_launch(ops, B, H, tile):
+    """conv_norm_out -> SiLU -> conv_out as ONE launch (aldm_gn_silu_conv3x3_small) against torch and against the two launches it
+    replaces: statistics from the producing convolution's table, zero padding applied to the ACTIVATION, every row count."""
+    g = torch.Generator().manual_seed(41)
+    W, C, Co = 16, 128, 8
+    x = bf(torch.randn(B, 64, H, W, generator=g))
+    w1 = bf(torch.randn(C, 64, 3, 3, generator=g) * 0.06)
+    b1 = torch.randn(C, generator=g)
+    y1 = ops.conv(nhwc(x), ops.pack_conv(w1.to(DEV), b1.to(DEV)), pad=(1, 1), tile=tile, ring=(3 if tile else 0), splits=1, qstats=True)
+    assert getattr(y1, "qstats", None) is not None
+    gm, bt = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    w2 = bf(torch.randn(Co, C, 3, 3, generator=g) * 0.05)
+    b2 = torch.randn(Co, generator=g)
+    pw = ops.pack_conv(w2.to(DEV), b2.to(DEV))
+    assert ops.gn_silu_conv_out_ok(y1, pw, 32)
+    got = ops.gn_silu_conv_out(y1, gm.to(DEV), bt.to(DEV), 32, 1e-5, pw)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (B, H, W, Co)
+    a = bf(F.silu(F.group_norm(to_nchw(y1).float(), 32, gm, bt, 1e-5)))               # the activation as the kernel rounds it (bf16 in LDS)
+    want = F.conv2d(a, w2, b2, padding=1)
+    close(got.permute(0, 3, 1, 2), want, rtol=2e-2)
+    two = ops.conv(ops.groupnorm(y1, gm.to(DEV), bt.to(DEV), 32, 1e-5, 1), pw, pad=(1, 1), out_f32=True)
+    close(got.permute(0, 3, 1, 2), two.permute(0, 3, 1, 2).float().cpu(), rtol=1e-2, atol=2e-2)
+
+
 def test_layernorm(ops):
     g = torch.Generator().manual_seed(8)
     for Cc in (64, 96, 256, 640):
