@@ -49,6 +49,9 @@ class IgemmArgs(C.Structure):
         ("qstat_out", C.c_void_p),
         ("x3", C.c_void_p), ("x4", C.c_void_p), ("Cin3", C.c_int), ("Cin4", C.c_int),
         ("vt_dual", C.c_int),
+        ("gnin_gamma", C.c_void_p), ("gnin_beta", C.c_void_p), ("gnin_q1", C.c_void_p), ("gnin_q2", C.c_void_p),
+        ("gnin_bm1", C.c_int), ("gnin_tpi1", C.c_int), ("gnin_bm2", C.c_int), ("gnin_tpi2", C.c_int),
+        ("gnin_groups", C.c_int), ("gnin_act", C.c_int), ("gnin_eps", C.c_float),
     ]
 
 

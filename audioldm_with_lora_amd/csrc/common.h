@@ -112,19 +112,20 @@ static inline long long cdivll(long long a, long long b) { return (a + b - 1) / 
 template <int BYTES>
 __device__ __forceinline__ void aldm_touch_kernargs() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(BYTES <= 512, "eight 64-byte lines");
-  // (one asm block: left to the compiler the eight loads come out as two or three waited groups)
+  static_assert(BYTES <= 640, "ten 64-byte lines");
+  // (one asm block: left to the compiler the loads come out as two or three waited groups)
   constexpr int LAST = (BYTES - 1) / 64 * 64;
 #define ALDM_KA_OFF(i) ((i) * 64 < LAST ? (i) * 64 : LAST)
   const void* ka = __builtin_amdgcn_kernarg_segment_ptr();
-  unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+  unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
   asm volatile(
-      "s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\t"
-      "s_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\t"
+      "s_load_dword %0, %10, %11\n\ts_load_dword %1, %10, %12\n\ts_load_dword %2, %10, %13\n\ts_load_dword %3, %10, %14\n\t"
+      "s_load_dword %4, %10, %15\n\ts_load_dword %5, %10, %16\n\ts_load_dword %6, %10, %17\n\ts_load_dword %7, %10, %18\n\t"
+      "s_load_dword %8, %10, %19\n\ts_load_dword %9, %10, %20\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9)
       : "s"(ka), "n"(ALDM_KA_OFF(0)), "n"(ALDM_KA_OFF(1)), "n"(ALDM_KA_OFF(2)), "n"(ALDM_KA_OFF(3)), "n"(ALDM_KA_OFF(4)),
-        "n"(ALDM_KA_OFF(5)), "n"(ALDM_KA_OFF(6)), "n"(ALDM_KA_OFF(7))
+        "n"(ALDM_KA_OFF(5)), "n"(ALDM_KA_OFF(6)), "n"(ALDM_KA_OFF(7)), "n"(ALDM_KA_OFF(8)), "n"(ALDM_KA_OFF(9))
       : "memory");
 #undef ALDM_KA_OFF
 #endif

@@ -119,6 +119,9 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     d.ln_s = p->ln_s; d.ln_sa = p->ln_sa; d.ln_ca = p->ln_ca; d.ln_eps = p->ln_eps;
     d.rowstat = p->rowstat_out; d.ln_parts = p->ln_parts; d.ln_np = p->ln_nparts;
     d.qstat = p->qstat_out; d.qtile = -1;
+    d.gi_gamma = p->gnin_gamma; d.gi_beta = p->gnin_beta; d.gi_q1 = p->gnin_q1; d.gi_q2 = p->gnin_q2;
+    d.gi_bm1 = p->gnin_bm1; d.gi_tpi1 = p->gnin_tpi1; d.gi_bm2 = p->gnin_bm2; d.gi_tpi2 = p->gnin_tpi2;
+    d.gi_groups = p->gnin_groups; d.gi_act = p->gnin_act; d.gi_eps = p->gnin_eps;
 #ifdef ALDM_DIAG
     d.diag = (p->splits <= 1) ? (unsigned long long*)p->workspace : nullptr;   // diagnostic build: workspace doubles as the stamp buffer
 #else
@@ -128,6 +131,16 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 
   int tile = p->tile ? p->tile : pick_tile(d.M, d.N);
+  if (p->gnin_gamma) {
+    ALDM_CHECK_ARG(tile == ALDM_TILE_HALO_128x128 || tile == ALDM_TILE_HALO_64x128, "igemm: gnin_* (GroupNorm of the input inside the launch) needs a halo tile");
+    const int Ct = p->Cin + p->Cin2;
+    ALDM_CHECK_ARG(p->gnin_beta && p->gnin_q1 && (p->Cin2 == 0 || p->gnin_q2) && p->gnin_groups > 0 && p->gnin_groups <= 64 && Ct % p->gnin_groups == 0 &&
+                   (Ct / p->gnin_groups) % 4 == 0 && Ct <= 512 && p->UH == 0 &&
+                   (p->gnin_tpi1 > 0 || (p->gnin_bm1 > 0 && p->gnin_bm1 <= p->IH * p->IW)) &&
+                   (p->Cin2 == 0 || p->gnin_tpi2 > 0 || (p->gnin_bm2 > 0 && p->gnin_bm2 <= p->IH * p->IW)) &&
+                   (p->gnin_act == ALDM_ACT_NONE || p->gnin_act == ALDM_ACT_SILU),
+                   "igemm: gnin_*: tables for every source, group width a multiple of 4, at most 512 input channels, no up-sampling, act NONE / SILU");
+  }
   const bool vt = p->vt != nullptr;
   int rc;
   switch (tile) {

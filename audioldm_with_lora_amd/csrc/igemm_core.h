@@ -66,6 +66,9 @@ struct IgemmDev {
   float* qstat; int qtile;    // GroupNorm hand-over: per (M-tile, image slot, 4-channel quad) partial (sum, sum of squares); qtile >= 0 overrides m0 / BM
   float* rowstat;             // producer side of the LayerNorm hand-over: [M][tiles_n][2] (sum, sum of squares) per output row and N-tile
   const float* ln_parts; int ln_np;   // consumer side: the producer's table, ln_np partial pairs per row
+  // GroupNorm (+ SiLU) of the input folded into the halo gather (igemm_halo.hip, GNIN instantiations); gi_gamma == nullptr: off
+  const float* gi_gamma; const float* gi_beta; const float* gi_q1; const float* gi_q2;
+  int gi_bm1, gi_tpi1, gi_bm2, gi_tpi2, gi_groups, gi_act; float gi_eps;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }

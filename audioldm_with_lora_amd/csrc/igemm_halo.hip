@@ -20,10 +20,17 @@
 // Serves ResnetBlock2D conv1 / conv2 and the up-sampler convs of UNet2DConditionModel.forward
 // [REF script/train/train_audioldm_lora.py:539-546], their dX in the LoRA trainer, and the same blocks of AutoencoderKL.
 #include "igemm_core.h"
+#include "gn_stats.h"
 
 namespace aldm_igemm_detail {
 
-template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, int EPI /* 0 full, 1 lean, 4 lean + statistics */>
+// GNIN: GroupNorm (+ SiLU) of the INPUT inside the launch (ResnetBlock2D norm1 / norm2).  The producing convolutions left their
+// per-tile (sum, sum of squares) tables next to the raw tensors (qstat_out); the prologue turns them into a per-channel (scale, shift)
+// table in LDS, and every halo chunk is normalised + activated IN PLACE once it has landed -- by the thread that DMA'd it, so the
+// wait it already does suffices -- before the barrier that releases it to the nine taps.  Padding pixels stay the zeros the DMA's
+// range check wrote (the convolution pads the ACTIVATION).  One 8 us groupnorm_apply launch and one write + read of the normalised
+// tensor disappear per ResnetBlock2D convolution at the 4000-pixel level.
+template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, int EPI /* 0 full, 1 lean, 4 lean + statistics */, bool GNIN = false>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(IgemmDev)>();
@@ -41,6 +48,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][halo: HP*64 x 128 B] [S][B: BN x 128 B]
   char* const Hs = smem;
   char* const Bring = smem + 2 * HALO_BYTES;
+  float* const gtab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + S * BSTAGE);   // GNIN: [512] scale | [512] shift | [64] mean | [64] rstd
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,6 +163,34 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(s, s);
+  if constexpr (GNIN) {
+    // statistics of this image's groups from the producers' tables, then (scale, shift) per input channel; under the first DMAs
+    // (gamma / beta of channel `tid` are requested first: fetched behind the statistics they would be one more dependent round trip)
+    const float my_gamma = tid < p.Ctot ? p.gi_gamma[tid] : 0.f, my_beta = tid < p.Ctot ? p.gi_beta[tid] : 0.f;
+    const int groups = p.gi_groups, Cg = p.Ctot / groups;
+    int lpg = 1;
+    while (lpg * 2 * groups <= NT && lpg < 64) lpg *= 2;
+    const GnSrc s1{p.x, p.gi_q1, p.Cin, p.gi_bm1, p.gi_tpi1}, s2{p.x2, p.gi_q2, p.Cin2, p.gi_bm2 > 0 ? p.gi_bm2 : 1, p.gi_tpi2};
+    const int HWs = p.IH * p.IW;
+    const int g = tid / lpg, j = tid - g * lpg;
+    float a = 0.f, q2 = 0.f;
+    if (g < groups) gn_group_sums(s1, s2, img, HWs, Cg, g, j, lpg, a, q2);
+    for (int o = 1; o < lpg; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
+    if (g < groups && j == 0) {
+      const float n = (float)HWs * (float)Cg;
+      const float mu = a / n;
+      gtab[1024 + g] = mu;
+      gtab[1088 + g] = rsqrtf(fmaxf(q2 / n - mu * mu, 0.f) + p.gi_eps);
+    }
+    __syncthreads();
+    if (tid < p.Ctot) {                                      // (Ctot <= 512 = NT, host-checked)
+      const int gg = tid / Cg;
+      const float sc = my_gamma * gtab[1088 + gg];
+      gtab[tid] = sc;
+      gtab[512 + tid] = my_beta - gtab[1024 + gg] * sc;
+    }
+    __syncthreads();
+  }
   {
     int st = 0, st_fill = D;
     int c_c = 0, c_tap = 0, c_dy = 0, c_dx = 0;          // compute-side cursor
@@ -168,6 +204,29 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
         halo_young = halo_young || ((t == 9 || t == 18) && item + d < nitems);
       }
       if (halo_young) wait_vmcnt<(D - 1) * W_PASSES + HP>(); else wait_vmcnt<(D - 1) * W_PASSES>();
+      if constexpr (GNIN) {
+        if (c_tap == 0) {                                    // (uniform) this item opens a chunk: normalise the chunks this thread DMA'd
+          const int cb = (c_c << 6) + kchunk * 8;            // first of the 8 channels in this thread's 16-byte slot
+          const f32x4 sc0 = *reinterpret_cast<const f32x4*>(gtab + cb), sc1 = *reinterpret_cast<const f32x4*>(gtab + cb + 4);
+          const f32x4 sh0 = *reinterpret_cast<const f32x4*>(gtab + 512 + cb), sh1 = *reinterpret_cast<const f32x4*>(gtab + 512 + cb + 4);
+          char* hb = Hs + (c_c & 1) * HALO_BYTES + wave * 1024 + lane * 16;
+#pragma unroll
+          for (int ps = 0; ps < HP; ++ps) {
+            if (h_pix[ps] >= 0) {
+              const bf16x8 v = *reinterpret_cast<const bf16x8*>(hb + ps * (RPP * 128));
+              bf16x8 o;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                float t = fmaf((float)v[k], k < 4 ? sc0[k & 3] : sc1[k & 3], k < 4 ? sh0[k & 3] : sh1[k & 3]);
+                if (p.gi_act == ALDM_ACT_SILU) t = silu_f(t);
+                o[k] = (bf16)t;
+              }
+              *reinterpret_cast<bf16x8*>(hb + ps * (RPP * 128)) = o;
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the rewritten chunks are in LDS before the barrier releases them
+        }
+      }
       __builtin_amdgcn_s_barrier();
       issue(item + D, st_fill);
       mma_tap(Hs + (c_c & 1) * HALO_BYTES, Bring + st * BSTAGE, c_dy * HW2 + c_dx);
@@ -189,13 +248,13 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int HP, int S, int EPI>
+template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false>
 int launch_halo_v(const IgemmDev& d, hipStream_t st) {
-  constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128;
+  constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128 + (GNIN ? (1024 + 128) * sizeof(float) : 0);
   constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
-  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI>;
+  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_halo")) return rc;
   const int rows_pt = BM / d.OW;
   if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
@@ -214,6 +273,13 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int HP, int S>
 int launch_halo(const IgemmDev& d, hipStream_t st) {
+  if (d.gi_gamma) {                                          // GroupNorm of the input folded in: the ResnetBlock2D convolutions (lean epilogues)
+    if (d.out_act != ALDM_ACT_NONE || d.post_act != ALDM_ACT_NONE) {
+      aldm_set_error("igemm_halo: gnin_* launches take no output activation");
+      return ALDM_E_UNSUPPORTED;
+    }
+    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4, true>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1, true>(d, st);
+  }
   if (d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE)
     return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1>(d, st);
   return launch_halo_v<BM, BN, WM, WN, HP, S, 0>(d, st);

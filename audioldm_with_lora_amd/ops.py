@@ -450,7 +450,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
          out_slope=0.0, res=None, res2=None, alpha=1.0, post_act=ACT_NONE, post_slope=0.0, out2=None, out=None, out_f32=False, out_ld=None, out_batch_stride=None,
          out_pix_stride=1, out_pix_offset=0, vt=None, vt_col0=0, vt_ld=0, vt_batch_stride=0, lora_t_out=None,
          splits=None, tile=0, ring=0, gn=None, gn_keep=False, defer=False, rowstats=False, ln_parts=None, x3=None, x4=None,
-         vt_dual=False, qstats=False):
+         vt_dual=False, qstats=False, gn_in=None):
     """Implicit-GEMM convolution over channels-last x [B, IH, IW, C1] (+ x2 [B, IH, IW, C2]).
 
     gn=(gamma, beta, groups, eps, act) returns GroupNorm(+act) of the convolution instead of the convolution: when the launch
@@ -459,6 +459,9 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
     -- ResnetBlock2D.conv2 (+ shortcut `res`) in front of a Transformer2DModel's norm: the block output stays on the residual
     stream and the fused kernel writes both.  defer=True: the same for a norm that is launched later by the caller -- returns
     a Deferred (see there) when the launch is split-K, else the tensor as usual.
+
+    gn_in=(gamma, beta, groups, eps, act): x (| x2) are RAW convolution outputs carrying `.qstats`; their GroupNorm (+ act) is applied
+    inside this launch, on the halo tile's way into LDS (gn_in_ok() says whether a launch can take it; a halo tile is then forced).
 
     LayerNorm hand-over (BasicTransformerBlock: h -> LayerNorm -> projection): rowstats=True returns (out, stats), stats fp32
     [M, N / BN, 2] = per-row partial (sum, sum of squares) written by the epilogue; a consumer packed with pack_linear_ln takes
@@ -578,7 +581,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
         sfx = (("" if splits is None else f" sp{splits}") + (" gn" if gn_defer else "") + (" rs" if rowstats else "")
-               + (" lp" if ln_parts is not None else "") + (f" e{C3}+{C4}" if x3 is not None else "") + (" vd" if vt_dual else ""))
+               + (" lp" if ln_parts is not None else "") + (f" e{C3}+{C4}" if x3 is not None else "") + (" vd" if vt_dual else "")
+               + (" gi" if gn_in is not None else ""))
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
@@ -595,6 +599,19 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             cfg = TUNER.choose(key, a, M, pw, ktiles, can_split and splits is None, splits, fast_path, vt is not None, x.device, halo)
         if cfg is not None:
             tile, ring, splits = cfg
+    if gn_in is not None:
+        # GroupNorm of the input inside the launch: halo tiles only (the tile is normalised once in LDS); statistics from the producers
+        q1, q2 = getattr(x, "qstats", None), (getattr(x2, "qstats", None) if x2 is not None else None)
+        if not gn_in_ok(x, x2, pw, stride, pad, dil, up_size, x3):
+            raise _lib.AldmError("conv: gn_in needs a 3x3 / stride 1 / pad 1 launch that fits a halo tile and inputs with .qstats (gn_in_ok)")
+        if tile not in HALO_ROWS:
+            tile, ring = (7 if (128 % OW == 0 and (128 // OW + 2) * (OW + 2) <= HALO_ROWS[7]) else 8), 0
+        splits = 1
+        gm_, bt_, a.gnin_groups, a.gnin_eps, a.gnin_act = gn_in
+        a.gnin_gamma, a.gnin_beta = gm_.data_ptr(), bt_.data_ptr()
+        a.gnin_q1, a.gnin_bm1, a.gnin_tpi1 = q1.table.data_ptr(), q1.bm, q1.tpi
+        if q2 is not None:
+            a.gnin_q2, a.gnin_bm2, a.gnin_tpi2 = q2.table.data_ptr(), q2.bm, q2.tpi
     if splits is None:
         splits = auto_splits(M, pw.N, ktiles) if (can_split and tile not in HALO_ROWS) else 1
     if tile == 0:
@@ -793,6 +810,25 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     check(_launch(f"groupnorm|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(
         _p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm")
     return y
+
+
+def gn_in_ok(x, x2, pw, stride=(1, 1), pad=(1, 1), dil=(1, 1), up_size=None, x3=None):
+    """Can a convolution apply the GroupNorm of its input itself (conv(gn_in=))?  3x3 / stride 1 / pad 1 on a halo tile, every source a
+    raw convolution output with its statistics table, channel counts multiples of 64, at most 512 input channels."""
+    if not isinstance(x, torch.Tensor) or getattr(x, "qstats", None) is None or x.dim() != 4:
+        return False
+    if x2 is not None and (not isinstance(x2, torch.Tensor) or getattr(x2, "qstats", None) is None):
+        return False
+    B, IH, IW, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    hw = IH * IW
+    for q in (x.qstats, x2.qstats if x2 is not None else None):
+        if q is not None and not (q.tpi > 0 or q.bm <= hw):
+            return False
+    fits = any(bm % IW == 0 and (bm // IW + 2) * (IW + 2) <= HALO_ROWS[t] for t, bm in ((7, 128), (8, 64)))
+    return (pw.KH == 3 and pw.KW == 3 and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and tuple(dil) == (1, 1) and up_size is None
+            and x3 is None and not pw.Rp and not pw.geglu and pw.ln_s is None and C1 % 64 == 0 and C2 % 64 == 0 and C1 + C2 <= 512
+            and pw.Cin == C1 + C2 and fits)
 
 
 def gn_silu_conv_out_ok(x, pw, groups):

@@ -240,18 +240,32 @@ def pack_transformer(t: Transformer2DModel):
 # ----------------------------------------------------------------------------------------------
 # launch sequences
 # ----------------------------------------------------------------------------------------------
+GN_IN = os.environ.get("ALDM_NO_GN_IN") is None    # GroupNorm of a convolution's input inside its halo tile (ops.conv gn_in=); the switch is an A/B aid
+
+
 def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=None):
     """ResnetBlock2D over x (| x2).  next_gn = (gamma, beta, groups, eps, act) of a GroupNorm that consumes the block output
     (the Transformer2DModel behind it): returns (output, its GroupNorm), the norm fused with conv2's split-K reduce.
     x may be an ops.Deferred (producer's split-K reduce pending): norm1 performs it.  defer = (channels, groups) of the norm
     that will consume THIS block's output next: conv2 may then return an ops.Deferred in turn."""
-    h = ops.groupnorm(x, P.g1, P.b1, P.groups, P.eps, ACT_SILU, x2=x2)
-    x = ops.tensor_of(x)
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
-    # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
-    # (qstats=True: a launch that does not split K leaves GroupNorm statistics next to its output, so the norm that consumes it --
-    #  here norm2, below the next block's norm1 / the Transformer2DModel's norm -- is one coalesced apply pass)
-    h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=(P.g2, P.b2, P.groups, P.eps, ACT_SILU), qstats=True)
+    gn2 = (P.g2, P.b2, P.groups, P.eps, ACT_SILU)
+    h1 = None                                  # conv1's RAW output when norm2 is left to conv2 (statistics attached)
+    if GN_IN and ops.gn_in_ok(x, x2, P.conv1):
+        # the 4000-pixel level: x (| x2) are raw convolution outputs with their statistics tables -- norm1 + SiLU happen inside conv1's
+        # halo tile (no groupnorm_apply launch, the normalised tensor never exists in HBM); conv1 leaves ITS statistics for norm2
+        h1 = ops.conv(x, P.conv1, x2=x2, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, qstats=True,
+                      gn_in=(P.g1, P.b1, P.groups, P.eps, ACT_SILU))
+        if not (P.conv2s is None and getattr(h1, "qstats", None) is not None and ops.gn_in_ok(h1, None, P.conv2)):
+            h, h1 = ops.groupnorm(h1, *gn2), None          # conv2 carries the fused shortcut segment (no halo tile): norm2 as a launch
+    else:
+        h = ops.groupnorm(x, P.g1, P.b1, P.groups, P.eps, ACT_SILU, x2=x2)
+        x = ops.tensor_of(x)
+        # conv1 -> norm2 -> SiLU; a split-K conv1 leaves its partial tiles to the GroupNorm kernel (no reduce launch)
+        # (qstats=True: a launch that does not split K leaves GroupNorm statistics next to its output, so the norm that consumes it --
+        #  here norm2, below the next block's norm1 / the Transformer2DModel's norm -- is one coalesced apply pass)
+        h = ops.conv(h, P.conv1, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, gn=gn2, qstats=True)
+    x = ops.tensor_of(x)
     if P.conv2s is not None and (x2 is None or x2.shape[3] % 64 == 0) and x.shape[3] % 64 == 0:
         # the 1x1 shortcut over the block input (| skip) rides at the end of conv2's K loop: one launch instead of two
         if next_gn is not None:
@@ -262,9 +276,10 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=No
     else:
         assert x2 is None
         xs = x
+    src, fold = (h1, dict(gn_in=gn2)) if h1 is not None else (h, {})      # (norm2 + SiLU inside conv2's halo tile)
     if next_gn is not None:
-        return ops.conv(h, P.conv2, pad=(1, 1), res=xs, gn=next_gn, gn_keep=True, qstats=True)
-    return ops.conv(h, P.conv2, pad=(1, 1), res=xs, defer=(defer or False), qstats=True)
+        return ops.conv(src, P.conv2, pad=(1, 1), res=xs, gn=next_gn, gn_keep=True, qstats=True, **fold)
+    return ops.conv(src, P.conv2, pad=(1, 1), res=xs, defer=(defer or False), qstats=True, **fold)
 
 
 def run_attention(P, hn, h_res, B, N, fp8=False, ln_parts=None, rowstats=False):

@@ -117,6 +117,12 @@ typedef struct {
      fused QKV GEMM needs q | k | v row-major (backward operands) and token-major (flash kernels' operands): one launch instead
      of a GEMM plus a transpose.  Standard epilogue only: no residual / activation / out2 on such a launch. */
   int vt_dual;
+  /* GroupNorm (+ activation) of the INPUT applied inside the launch (halo tiles only): x (| x2) hold the raw output of the producing
+     convolution(s), gnin_q1 (| gnin_q2) their qstat_out tables (gnin_bm / gnin_tpi as aldm_groupnorm_apply's bm / tpi); the halo tile is
+     normalised + activated once on its way into LDS, so ResnetBlock2D's norm1 / norm2 need no launch and no round trip of the
+     normalised tensor through HBM.  gnin_gamma / gnin_beta have Cin + Cin2 entries.  NULL gnin_gamma = off. */
+  const float* gnin_gamma; const float* gnin_beta; const float* gnin_q1; const float* gnin_q2;
+  int gnin_bm1, gnin_tpi1, gnin_bm2, gnin_tpi2, gnin_groups, gnin_act; float gnin_eps;
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,

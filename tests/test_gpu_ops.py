@@ -371,6 +371,43 @@ def test_gn_silu_conv_out_one_launch(ops, B, H, tile):
     close(got.permute(0, 3, 1, 2), two.permute(0, 3, 1, 2).float().cpu(), rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("B,H,C1,C2,N,res", [(2, 250, 128, 0, 128, True), (2, 250, 256, 128, 128, False), (1, 130, 128, 128, 128, False),
+                                               (2, 250, 128, 0, 256, False)])
+def test_conv_applies_groupnorm_of_its_input(ops, B, H, C1, C2, N, res):
+    """ops.conv(gn_in=): ResnetBlock2D norm1 / norm2 + SiLU inside the consuming convolution's halo tile (statistics from the
+    producers' tables, concatenated sources, groups that straddle the concatenation) against torch and against the two launches."""
+    g = torch.Generator().manual_seed(43)
+    W = 16
+    x0 = bf(torch.randn(B, 64, H, W, generator=g))
+    def producer(co):
+        w = bf(torch.randn(co, 64, 3, 3, generator=g) * 0.06)
+        b = torch.randn(co, generator=g)
+        y = ops.conv(nhwc(x0), ops.pack_conv(w.to(DEV), b.to(DEV)), pad=(1, 1), splits=1, qstats=True)
+        assert getattr(y, "qstats", None) is not None
+        return y
+    y1 = producer(C1)
+    y2 = producer(C2) if C2 else None
+    C = C1 + C2
+    gm, bt = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    w = bf(torch.randn(N, C, 3, 3, generator=g) * 0.03)
+    b = torch.randn(N, generator=g)
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    r = bf(torch.randn(B, N, H, W, generator=g)) if res else None
+    rb = torch.randn(B, N, generator=g)
+    assert ops.gn_in_ok(y1, y2, pw)
+    kw = dict(pad=(1, 1), rowbias=rb.to(DEV), rowbias_ld=N, res=(nhwc(r) if res else None))
+    got = ops.conv(y1, pw, x2=y2, gn_in=(gm.to(DEV), bt.to(DEV), 32, 1e-5, 1), qstats=True, **kw)
+    assert getattr(got, "qstats", None) is not None                       # and it hands ITS statistics on
+    xin = torch.cat([to_nchw(y1)] + ([to_nchw(y2)] if C2 else []), 1)
+    a = bf(F.silu(F.group_norm(xin, 32, gm, bt, 1e-5)))
+    want = F.conv2d(a, w, b, padding=1) + rb[:, :, None, None] + (r if res else 0)
+    close(to_nchw(got), want, rtol=2e-2)
+    two = ops.conv(ops.groupnorm(y1, gm.to(DEV), bt.to(DEV), 32, 1e-5, 1, x2=y2), pw, **kw)
+    close(to_nchw(got), to_nchw(two), rtol=1e-2, atol=3e-2)
+    nxt = ops.groupnorm(got, torch.ones(N).to(DEV), torch.zeros(N).to(DEV), 32, 1e-5, 0)      # consumer of the handed-over statistics
+    close(to_nchw(nxt), F.group_norm(to_nchw(got), 32, None, None, 1e-5), rtol=2e-2)
+
+
 def test_layernorm(ops):
     g = torch.Generator().manual_seed(8)
     for Cc in (64, 96, 256, 640):
