@@ -243,6 +243,13 @@ def pack_transformer(t: Transformer2DModel):
 GN_IN = os.environ.get("ALDM_NO_GN_IN") is None    # GroupNorm of a convolution's input inside its halo tile (ops.conv gn_in=); the switch is an A/B aid
 
 
+def _gn_in_pays(x, x2, pw):
+    """Policy on top of ops.gn_in_ok (capability): the fold forces a halo tile, which is the right tile for the UNet's 4000-pixel level
+    (128 output channels, 128 - 384 input channels: -3 .. -12 us per convolution) but not for the VAE's 512 -> 512 convolutions at
+    250 x 16 (the 128x128 tile runs them at 898 TFLOP/s, the halo tile at 574: +47 us per launch against 23 us of apply pass saved)."""
+    return GN_IN and pw.N <= 128 and pw.Cin <= 384 and ops.gn_in_ok(x, x2, pw)
+
+
 def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=None):
     """ResnetBlock2D over x (| x2).  next_gn = (gamma, beta, groups, eps, act) of a GroupNorm that consumes the block output
     (the Transformer2DModel behind it): returns (output, its GroupNorm), the norm fused with conv2's split-K reduce.
@@ -251,12 +258,12 @@ def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=No
     rb = rowbias[:, P.temb_off:] if rowbias is not None else None
     gn2 = (P.g2, P.b2, P.groups, P.eps, ACT_SILU)
     h1 = None                                  # conv1's RAW output when norm2 is left to conv2 (statistics attached)
-    if GN_IN and ops.gn_in_ok(x, x2, P.conv1):
+    if _gn_in_pays(x, x2, P.conv1):
         # the 4000-pixel level: x (| x2) are raw convolution outputs with their statistics tables -- norm1 + SiLU happen inside conv1's
         # halo tile (no groupnorm_apply launch, the normalised tensor never exists in HBM); conv1 leaves ITS statistics for norm2
         h1 = ops.conv(x, P.conv1, x2=x2, pad=(1, 1), rowbias=rb, rowbias_ld=rowbias_ld, qstats=True,
                       gn_in=(P.g1, P.b1, P.groups, P.eps, ACT_SILU))
-        if not (P.conv2s is None and getattr(h1, "qstats", None) is not None and ops.gn_in_ok(h1, None, P.conv2)):
+        if not (P.conv2s is None and getattr(h1, "qstats", None) is not None and _gn_in_pays(h1, None, P.conv2)):
             h, h1 = ops.groupnorm(h1, *gn2), None          # conv2 carries the fused shortcut segment (no halo tile): norm2 as a launch
     else:
         h = ops.groupnorm(x, P.g1, P.b1, P.groups, P.eps, ACT_SILU, x2=x2)
