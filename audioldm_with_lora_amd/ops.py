@@ -605,7 +605,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         if not gn_in_ok(x, x2, pw, stride, pad, dil, up_size, x3):
             raise _lib.AldmError("conv: gn_in needs a 3x3 / stride 1 / pad 1 launch that fits a halo tile and inputs with .qstats (gn_in_ok)")
         if tile not in HALO_ROWS:
-            tile, ring = (7 if (128 % OW == 0 and (128 // OW + 2) * (OW + 2) <= HALO_ROWS[7]) else 8), 0
+            tile, ring = (7 if (128 % OW == 0 and (128 // OW + 2) * (OW + 2) <= HALO_ROWS[7]) else 8), GNIN_RING
         splits = 1
         gm_, bt_, a.gnin_groups, a.gnin_eps, a.gnin_act = gn_in
         a.gnin_gamma, a.gnin_beta = gm_.data_ptr(), bt_.data_ptr()
@@ -810,6 +810,9 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None):
     check(_launch(f"groupnorm|HW{H * W} C{C1 + C2}", 10.0 * n, 4.0 * n, lambda: lib.aldm_groupnorm(
         _p(x), _p(x2), B, H * W, C1, C2, groups, eps, _p(gamma), _p(beta), act, _p(y), _stream())), "aldm_groupnorm")
     return y
+
+
+GNIN_RING = int(os.environ.get("ALDM_GNIN_RING", "0"))     # LDS-DMA ring depth of the input-norm-folding halo launches (0: pick_ring); tuning aid
 
 
 def gn_in_ok(x, x2, pw, stride=(1, 1), pad=(1, 1), dil=(1, 1), up_size=None, x3=None):

@@ -22,4 +22,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG
 python3 tools/pmc_traffic.py $OUT/prof_${TAG}_fetch/f_counter_collection.csv $OUT/prof_${TAG}_write/w_counter_collection.csv > $OUT/${TAG}_pmc_traffic.json
 echo "[profile] PMC traffic done"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/prof_${TAG}_sq -o s -- python3 $PB > $OUT/prof_${TAG}_sq.log 2>&1 || echo "[profile] SQ pass failed (counter names?)"
-ls $OUT/prof_${TAG}_sq 2>/dev/null | head -3
+python3 tools/pmc_sq.py $OUT/prof_${TAG}_sq/s_counter_collection.csv attention_kernel igemm groupnorm pgemm attn_block64 ddim gn_silu > $OUT/${TAG}_pmc_sq.json || echo "[profile] pmc_sq.py failed"
+# the raw traces are hundreds of MB (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf $OUT/prof_${TAG} $OUT/prof_${TAG}_train $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write $OUT/prof_${TAG}_sq
+echo "[profile] done"
