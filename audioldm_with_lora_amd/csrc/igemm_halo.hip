@@ -299,6 +299,13 @@ int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, h
     return ALDM_E_UNSUPPORTED;
   }
   if (tile == ALDM_TILE_HALO_128x128) {
+    // halo rows the tile needs: (128 / OW + 2) image rows of OW + 2 pixels.  192 (three DMA passes) covers OW <= 16 -- the UNet's
+    // latents; the VAE's 64-wide images need 264: five passes, 80 KB for the two halo buffers
+    if ((128 / d.OW + 2) * (d.OW + 2) > 192) {
+      if (ring == 2) return launch_halo<128, 128, 4, 2, 5, 2>(d, st);
+      if (ring == 4) return launch_halo<128, 128, 4, 2, 5, 4>(d, st);
+      return launch_halo<128, 128, 4, 2, 5, 3>(d, st);
+    }
     if (ring == 2) return launch_halo<128, 128, 4, 2, 3, 2>(d, st);
     if (ring == 4) return launch_halo<128, 128, 4, 2, 3, 4>(d, st);
     return launch_halo<128, 128, 4, 2, 3, 3>(d, st);

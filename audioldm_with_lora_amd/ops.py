@@ -202,7 +202,7 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
 
 
 TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128)}
-HALO_ROWS = {7: 192, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip)
+HALO_ROWS = {7: 320, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip; 128x128: three or five DMA passes)
 
 
 def halo_tiles(OW, eligible):

@@ -247,7 +247,13 @@ def _gn_in_pays(x, x2, pw):
     """Policy on top of ops.gn_in_ok (capability): the fold forces a halo tile, which is the right tile for the UNet's 4000-pixel level
     (128 output channels, 128 - 384 input channels: -3 .. -12 us per convolution) but not for the VAE's 512 -> 512 convolutions at
     250 x 16 (the 128x128 tile runs them at 898 TFLOP/s, the halo tile at 574: +47 us per launch against 23 us of apply pass saved)."""
-    return GN_IN and pw.N <= 128 and pw.Cin <= 384 and ops.gn_in_ok(x, x2, pw)
+    if not (GN_IN and pw.N <= 128 and pw.Cin <= 384 and ops.gn_in_ok(x, x2, pw)):
+        return False
+    # every workgroup sums its image's producer tiles in its prologue: fine for the latent's 32 - 63 tiles, ruinous for a VAE mel image
+    # of 512 (measured: 630 us per convolution against 217 + 81 for convolution + apply pass) -- same bound as aldm_groupnorm_apply's
+    # finalize launch
+    hw = x.shape[1] * x.shape[2]
+    return all((q.tpi if q.tpi > 0 else hw // q.bm + 1) < ops.GN_FINALIZE_MIN_TILES for q in (x.qstats, x2.qstats if x2 is not None else None) if q is not None)
 
 
 def run_resnet(P, x, x2=None, rowbias=None, rowbias_ld=0, next_gn=None, defer=None):
