@@ -1,3 +1,6 @@
+"""Race hunt for the fused q | k | v launch of aldm_pgemm (section 5 of DESIGN.md, round 3): cold launches from an idle GPU against a
+reference run, reporting which output columns differ.  With the library built with -DPG_VERIFY the kernel also counts, after its first
+barrier, the LDS-resident operands that do not match global memory (aldm_pgemm_set_diag).  usage: python tools/dbg_qkv.py"""
 import math, sys, os, torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

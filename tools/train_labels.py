@@ -1,3 +1,5 @@
+"""One eager LoRA training step (config 3) with a hipEvent pair around every C-ABI launch: launches and time per label.
+usage: python tools/train_labels.py"""
 import collections, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
