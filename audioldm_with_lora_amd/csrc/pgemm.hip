@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
     } else if constexpr (EPI == EPI_VT) {
       mfma_vt();
     }
-#ifdef PG_VERIFY   // race hunt (tools/_dbg_qkv.py): after the first barrier, is every DMA'd operand really in LDS?  counts mismatches
+#ifdef PG_VERIFY   // race hunt (tools/dbg_qkv.py): after the first barrier, is every DMA'd operand really in LDS?  counts mismatches
     if (t == 0 && p.diag) {
       for (int j = tid; j < BNW; j += NTHR) {
         if (p.bias && cvec[j] != p.bias[n_wg0 + j]) atomicAdd(&p.diag[48], 1ull);
