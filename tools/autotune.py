@@ -105,9 +105,10 @@ def main():
         default = tuner.cands[key][0]
         if best != default:
             changed += 1
-            gain += (t_def - t_best)
+            if t_def is not None:                            # (the default slot of a launch whose tile the caller forces -- gn_in -- is never timed)
+                gain += (t_def - t_best)
             ops.TUNED[key] = best
-            print(f"[autotune] {key}: {default} {t_def * 1e3:.1f} us -> {best} {t_best * 1e3:.1f} us", flush=True)
+            print(f"[autotune] {key}: {default} {(t_def or 0.0) * 1e3:.1f} us -> {best} {t_best * 1e3:.1f} us", flush=True)
     ops.save_tuned()
     print(f"[autotune] wrote {ops.TUNED_PATH}: {changed} of {len(res)} GEMMs leave the heuristic (sum of per-launch gains {gain * 1e3:.0f} us)")
 
