@@ -15,6 +15,7 @@
 //   * softmax as in attention.hip: Q arrives pre-scaled by d^-0.5 log2(e) (folded into to_q by the host), the running maximum
 //     is the MFMA's initial accumulator and is only raised when a tile exceeds it by RESCALE_THR, the row sum rides in an
 //     extra d-tile whose first V^T row is ones.
+#include <cstdlib>
 #include "igemm_core.h"   // make_rsrc / lds_ptr_t / wait_vmcnt
 
 namespace {
@@ -36,7 +37,11 @@ struct WideCfg {
   static constexpr int DTL = DP / 16 + 1;                   // d-tiles of O^T incl. the ones tile
 };
 
-template <int DP, int NW>
+// QT query tiles of 16 per wave (round 3: QT = 2).  With one tile every wave reads the whole K tile (32 KB) and V^T tile (33 KB) from
+// LDS for 65 MFMAs: four waves need 2080 LDS cycles per key tile against 1040 MFMA cycles each -- LDS-read-bound by 2x.  Two query
+// tiles share every K / V^T fragment (the A operands): the same 65 KB now feed 130 MFMAs and the two pipes are balanced.  O^T and the
+// Q fragments double (264 + 128 VGPRs at d = 512): one wave per SIMD, which the 130 KB of LDS imposed anyway.
+template <int DP, int NW, int QT>
 __global__ __launch_bounds__(64 * NW) void attention_wide_kernel(const bf16* __restrict__ q, int ldq, const bf16* __restrict__ k, int ldk,
                                                                  const bf16* __restrict__ vt, int vt_ld, long long vt_bs, int N,
                                                                  bf16* __restrict__ out, int out_ld) {
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(64 * NW) void attention_wide_kernel(const bf16* __r
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int b = blockIdx.y;
-  const int q0 = (blockIdx.x * NW + wave) * 16;
+  const int q0 = (blockIdx.x * NW + wave) * 16 * QT;
   const bf16* qb = q + (long long)b * N * ldq;
   const bf16* kb = k + (long long)b * N * ldk;
   const bf16* vb = vt + (long long)b * vt_bs;
@@ -96,16 +101,22 @@ __global__ __launch_bounds__(64 * NW) void attention_wide_kernel(const bf16* __r
   };
 
   // Q fragments (B operand of S^T): lane (n, g) holds Q[q0 + n][32 ks + 8 g .. + 7]
-  bf16x8 qf[DKS];
+  bf16x8 qf[QT][DKS];
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int ks = 0; ks < DKS; ++ks)
-    qf[ks] = (q0 + n < N) ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + n) * ldq + 32 * ks + 8 * g) : zero8;
-
-  f32x4 o[DTL];
+  for (int u = 0; u < QT; ++u)
 #pragma unroll
-  for (int t = 0; t < DTL; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = 0.f;
+    for (int ks = 0; ks < DKS; ++ks)
+      qf[u][ks] = (q0 + 16 * u + n < N) ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + 16 * u + n) * ldq + 32 * ks + 8 * g) : zero8;
+
+  f32x4 o[QT][DTL];
+#pragma unroll
+  for (int u = 0; u < QT; ++u)
+#pragma unroll
+    for (int t = 0; t < DTL; ++t) o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT];
+#pragma unroll
+  for (int u = 0; u < QT; ++u) m_run[u] = 0.f;
 
   const int ntiles = (N + KT - 1) / KT;
   issue(0, 0);
@@ -120,54 +131,61 @@ __global__ __launch_bounds__(64 * NW) void attention_wide_kernel(const bf16* __r
     const char* Vb = Vs + buf * Cfg::VBYTES;
     const bool first = tile == 0;
 
-    // ---- S'^T = K Q^T - m_run : two stacked 16-key tiles ----
-    f32x4 s[2];
-    const float a0 = -m_run;
+    // ---- S'^T = K Q^T - m_run : two stacked 16-key tiles, every K fragment shared by the QT query tiles ----
+    f32x4 s[QT][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      s[sub] = f32x4{a0, a0, a0, a0};
+#pragma unroll
+      for (int u = 0; u < QT; ++u) { const float a0 = -m_run[u]; s[u][sub] = f32x4{a0, a0, a0, a0}; }
       const int row = sub * 16 + n;                          // A operand: lane (m = n, g) holds K[key row][32 ks + 8 g ..]
 #pragma unroll
       for (int ks = 0; ks < DKS; ++ks) {
         const int ph = (4 * ks + g) ^ (row & 15);
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kb + row * Cfg::KROW + ph * 16);
-        s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], s[u][sub], 0, 0, 0);
       }
     }
     const int kv0 = tile * KT;
     if (kv0 + KT > N) {                                      // tail: keys >= N
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+      for (int u = 0; u < QT; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (kv0 + sub * 16 + 4 * g + j >= N) s[sub][j] = -INFINITY;
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kv0 + sub * 16 + 4 * g + j >= N) s[u][sub][j] = -INFINITY;
     }
     // ---- softmax: this lane holds 8 of the 32 keys of query n; the other 24 sit in lanes n + 16 g' ----
-    float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (first || !__all(mx <= WIDE_RESCALE_THR)) {
-      const float delta = first ? mx : fmaxf(mx, 0.f);
-      m_run += delta;
-      if (!first) {
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
+    bf16x8 pf[QT];                                           // B operand of O^T += V^T P^T: k slots = keys {4g+j} then {16+4g+j}
 #pragma unroll
-        for (int t = 0; t < DTL; ++t)
+    for (int u = 0; u < QT; ++u) {
+      float mx = fmaxf(fmaxf(fmaxf(s[u][0][0], s[u][0][1]), fmaxf(s[u][0][2], s[u][0][3])),
+                       fmaxf(fmaxf(s[u][1][0], s[u][1][1]), fmaxf(s[u][1][2], s[u][1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (first || !__all(mx <= WIDE_RESCALE_THR)) {
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        m_run[u] += delta;
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[t][j] *= alpha;
+          for (int t = 0; t < DTL; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[u][t][j] *= alpha;
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[u][sub][j] -= delta;
       }
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[sub][j] -= delta;
+        for (int j = 0; j < 4; ++j) pf[u][sub * 4 + j] = (bf16)__builtin_amdgcn_exp2f(s[u][sub][j]);
     }
-    bf16x8 pf;                                               // B operand of O^T += V^T P^T: k slots = keys {4g+j} then {16+4g+j}
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pf[sub * 4 + j] = (bf16)__builtin_amdgcn_exp2f(s[sub][j]);
 
-    // ---- O^T += V^T P^T : A operand lane (m = n, g) holds V^T[16 t + n][keys 4g..4g+3 | 16+4g..16+4g+3] ----
+    // ---- O^T += V^T P^T : A operand lane (m = n, g) holds V^T[16 t + n][keys 4g..4g+3 | 16+4g..16+4g+3], shared by the query tiles ----
 #pragma unroll
     for (int t = 0; t < DTL; ++t) {
       const int row = t * 16 + n;
@@ -176,36 +194,40 @@ __global__ __launch_bounds__(64 * NW) void attention_wide_kernel(const bf16* __r
       const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((g >> 1)) ^ sw) * 16);
       const uint2 hi = *reinterpret_cast<const uint2*>(vrow + ((2 + (g >> 1)) ^ sw) * 16);
       const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < QT; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], o[u][t], 0, 0, 0);
     }
     wait_vmcnt<0>();                                         // the next tile has landed (it flew under ~65 MFMAs)
     __syncthreads();
   }
 
-  // ---- normalise and store: lane holds O^T[16 t + 4 g + j][q0 + n]; l = row DP of the ones tile (lanes g = 0, j = 0) ----
-  float l = o[DTL - 1][0];                                   // zero on the g != 0 lanes (rows DP + 4g: zero padding)
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
-  if (q0 + n < N) {
-    bf16* orow = out + ((long long)b * N + q0 + n) * out_ld;
+  // ---- normalise and store: lane holds O^T[16 t + 4 g + j][q0 + 16 u + n]; l = row DP of the ones tile (lanes g = 0, j = 0) ----
 #pragma unroll
-    for (int t = 0; t < DTL - 1; ++t) {
-      const bf16x4 v = {(bf16)(o[t][0] * inv), (bf16)(o[t][1] * inv), (bf16)(o[t][2] * inv), (bf16)(o[t][3] * inv)};
-      *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = v;
+  for (int u = 0; u < QT; ++u) {
+    float l = o[u][DTL - 1][0];                              // zero on the g != 0 lanes (rows DP + 4g: zero padding)
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + 16 * u + n < N) {
+      bf16* orow = out + ((long long)b * N + q0 + 16 * u + n) * out_ld;
+#pragma unroll
+      for (int t = 0; t < DTL - 1; ++t) {
+        const bf16x4 v = {(bf16)(o[u][t][0] * inv), (bf16)(o[u][t][1] * inv), (bf16)(o[u][t][2] * inv), (bf16)(o[u][t][3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = v;
+      }
     }
   }
 #endif
 }
 
-template <int DP, int NW>
+template <int DP, int NW, int QT>
 int launch_wide(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N, void* out,
                 int out_ld, hipStream_t st) {
   using Cfg = WideCfg<DP>;
-  auto kern = attention_wide_kernel<DP, NW>;
+  auto kern = attention_wide_kernel<DP, NW, QT>;
   static unsigned long long attr_done = 0;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), Cfg::LDS, &attr_done, "attention_wide")) return rc;
-  dim3 grid(cdiv(N, 16 * NW), B);
+  dim3 grid(cdiv(N, 16 * NW * QT), B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), Cfg::LDS, st, (const bf16*)q, ldq, (const bf16*)k, ldk, (const bf16*)vt, vt_ld, vt_bs, N,
                      (bf16*)out, out_ld);
   return aldm_launch_status("attention_wide");
@@ -221,10 +243,17 @@ extern "C" int aldm_attention_wide(const void* q, int ldq, const void* k, int ld
   ALDM_CHECK_ARG(vt_ld % 32 == 0 && vt_ld >= (N + 31) / 32 * 32, "attention_wide: vt_ld %d must be a multiple of 32 covering N %d (zero padded)", vt_ld, N);
   ALDM_CHECK_ARG((long long)N * ldk * 2 < 0x7FFFFFFFll && (long long)d * vt_ld * 2 < 0x7FFFFFFFll, "attention_wide: operands exceed 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
-  // 4 waves = 64 queries per workgroup: N = 4000 x 4 clips -> 252 workgroups, one per CU (130 KiB of LDS each at d = 512)
-  if (d == 512) return launch_wide<512, 4>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st);
-  if (d == 256) return launch_wide<256, 4>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st);
-  if (d == 128) return launch_wide<128, 4>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st);
+  // 4 waves = 64 (or 128) queries per workgroup: N = 4000 x 4 clips -> 252 workgroups, one per CU (130 KiB of LDS each at d = 512)
+  static const int qt_env = getenv("ALDM_WIDE_QT") ? atoi(getenv("ALDM_WIDE_QT")) : 0;   // tuning aid: query tiles per wave (1 / 2)
+  // two query tiles per wave once that still fills the chip: encode (8 x 4096 tokens: 256 workgroups) 0.79 -> 0.49 ms; decode
+  // (4 x 4000: 128 workgroups on 256 CUs) would go 0.32 -> 0.38 and keeps one
+  const bool two = qt_env ? qt_env == 2 : (long long)cdiv(N, 128) * B >= 192;
+  if (d == 512) return two ? launch_wide<512, 4, 2>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st)
+                           : launch_wide<512, 4, 1>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st);
+  if (d == 256) return two ? launch_wide<256, 4, 2>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st)
+                           : launch_wide<256, 4, 1>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st);
+  if (d == 128) return two ? launch_wide<128, 4, 2>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st)
+                           : launch_wide<128, 4, 1>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, out, out_ld, st);
   aldm_set_error("attention_wide: head dim %d (128 / 256 / 512 are built)", d);
   return ALDM_E_UNSUPPORTED;
 }
