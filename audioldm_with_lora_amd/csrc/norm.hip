@@ -26,6 +26,19 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nth
   return t;
 }
 
+// two sums with ONE pair of barriers (red: 2 x nthreads / 64 floats)
+__device__ __forceinline__ void block_sum_pair(float& a, float& b, float* red, int tid, int nthreads) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();
+  const int nw = nthreads / 64;
+  if ((tid & 63) == 0) { red[tid >> 6] = a; red[nw + (tid >> 6)] = b; }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+  for (int i = 0; i < nw; ++i) { ta += red[i]; tb += red[nw + i]; }
+  a = ta; b = tb;
+}
+
 // One workgroup per (batch, group).  A "quad" is 4 consecutive channels of one pixel (8 bytes); every
 // group width used by the models is a multiple of 4 and so is the concat boundary C1.
 __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x2,
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
                                                                    const float* __restrict__ beta, int act,
                                                                    bf16* __restrict__ y, AldmDiv dqpp) {
   aldm_touch_kernargs<96>();                // 84 bytes of explicit arguments: both lines in one round (common.h)
-  __shared__ float red[GN_THREADS / 64];
+  __shared__ float red[2 * GN_THREADS / 64];
   __shared__ __attribute__((aligned(16))) float sgm[GN_MAXCG], sbt[GN_MAXCG];
   const int C = C1 + C2;
   const int Cg = C / groups, qpp = Cg >> 2;
@@ -109,6 +122,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
   // the group's gamma / beta go to LDS now, under the strip's loads (visible after the first reduction's barrier): fetched per
   // output quad they were a load -> wait -> compute -> store chain of QPT L2 round trips at the END of the kernel
   if (tid < Cg) { sgm[tid] = gamma[c0 + tid]; sbt[tid] = beta[c0 + tid]; }
+  const float pivot = (float)((c0 < C1) ? x[(long long)b * HW * C1 + c0] : x2[(long long)b * HW * C2 + (c0 - C1)]);
 
   bf16x4 v[QPT];
   float s = 0.f;
@@ -124,20 +138,22 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
     }
     v[i] = t;
   }
-#pragma unroll
-  for (int i = 0; i < QPT; ++i) s += (float)v[i][0] + (float)v[i][1] + (float)v[i][2] + (float)v[i][3];
-  const float n = (float)nquads * 4.f;
-  const float mean = block_sum(s, red, tid, GN_THREADS) / n;
+  // mean and variance from ONE reduction: sums of (x - p) and (x - p)^2 around a pivot p every thread knows without a barrier -- the
+  // strip's first element (requested with the strip).  Shifted, the one-pass variance has no cancellation problem when |mean| >> std;
+  // the second reduction (two more barriers, ~0.4 us of a 6 us launch) is gone.
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     if (tid + i * GN_THREADS < nquads) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const float d = (float)v[i][k] - mean; ss += d * d; }
+      for (int k = 0; k < 4; ++k) { const float d = (float)v[i][k] - pivot; s += d; ss = fmaf(d, d, ss); }
     }
   }
-  const float var = block_sum(ss, red, tid, GN_THREADS) / n;
-  const float rstd = rsqrtf(var + eps);
+  const float n = (float)nquads * 4.f;
+  block_sum_pair(s, ss, red, tid, GN_THREADS);
+  const float dm = s / n;
+  const float mean = pivot + dm;
+  const float rstd = rsqrtf(fmaxf(ss / n - dm * dm, 0.f) + eps);
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * GN_THREADS;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
   aldm_touch_kernargs<160>();               // 148 bytes of explicit arguments: all three lines in one round (common.h)
   // C = channels of the partial tiles (first source); C2 more channels come as plain bf16 from x2 (torch.cat([h, skip]) in
   // front of an up-block ResnetBlock2D's norm1).  A group lies wholly in one source (host-checked: C % group width == 0).
-  __shared__ float red[GN_THREADS / 64];
+  __shared__ float red[2 * GN_THREADS / 64];
   __shared__ __attribute__((aligned(16))) float sgm[GN_MAXCG], sbt[GN_MAXCG], sadd[GN_MAXCG];
   const int Ct = C + C2;
   const int Cg = Ct / groups, qpp = Cg >> 2;
@@ -248,7 +264,8 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
     }
   }
   __syncthreads();                              // sadd / sgm / sbt are in LDS
-  float s = 0.f;
+  const float pivot = sadd[0];
+  float s = 0.f, ss = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     if (tid + i * GN_THREADS < nquads) {
@@ -264,20 +281,17 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
         for (int k = 0; k < 4; ++k) o[k] = (bf16)v[i][k];
         *reinterpret_cast<bf16x4*>(sum_out + off[i]) = o;
       }
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - pivot; s += d; ss = fmaf(d, d, ss); }
     }
   }
+  // (one reduction for mean and variance, shifted by the group's first bias + row bias -- the part of the values that can be large
+  //  against their spread; see groupnorm_reg_kernel)
   const float n = (float)nquads * 4.f;
-  const float mean = block_sum(s, red, tid, GN_THREADS) / n;
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < QPT; ++i) {
-    if (tid + i * GN_THREADS < nquads) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; ss += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(block_sum(ss, red, tid, GN_THREADS) / n + eps);
+  block_sum_pair(s, ss, red, tid, GN_THREADS);
+  const float dm = s / n;
+  const float mean = pivot + dm;
+  const float rstd = rsqrtf(fmaxf(ss / n - dm * dm, 0.f) + eps);
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     if (tid + i * GN_THREADS < nquads) {

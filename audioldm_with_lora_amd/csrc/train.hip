@@ -57,9 +57,10 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
   // the group's gamma / beta through LDS (visible after the first reduction's barrier): read per element from global they were
   // 4-byte loads with a wait each, in both sweeps
   if (tid < Cg) { sgm[tid] = gamma[c0 + tid]; sbt[tid] = beta[c0 + tid]; }
+  const float pivot = (float)((c0 < C1) ? x[(long long)b * HW * C1 + c0] : x2[(long long)b * HW * C2 + (c0 - C1)]);
 
   bf16x4 v[QPT], d[QPT], pa[QPT];                       // pa: the gradient x / x2 already hold (dx_acc / dx2_acc), requested with the strip
-  float s = 0.f, dummy = 0.f;
+  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int q = tid + i * NT;
@@ -92,21 +93,20 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_kernel(const bf16* __restric
     }
     v[i] = t;
     d[i] = u;
-    s += (float)t[0] + (float)t[1] + (float)t[2] + (float)t[3];
   }
-  const float n = (float)nquads * 4.f;
-  block_sum2<NT>(s, dummy, red, tid);
-  const float mean = s / n;
+  // mean and variance from one reduction, shifted by the strip's first element (see groupnorm_reg_kernel in norm.hip)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < QPT; ++i)
     if (tid + i * NT < nquads) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const float e = (float)v[i][k] - mean; ss += e * e; }
+      for (int k = 0; k < 4; ++k) { const float e = (float)v[i][k] - pivot; s += e; ss = fmaf(e, e, ss); }
     }
-  dummy = 0.f;
-  block_sum2<NT>(ss, dummy, red, tid);
-  const float rstd = rsqrtf(ss / n + eps);
+  const float n = (float)nquads * 4.f;
+  block_sum2<NT>(s, ss, red, tid);
+  const float dm = s / n;
+  const float mean = pivot + dm;
+  const float rstd = rsqrtf(fmaxf(ss / n - dm * dm, 0.f) + eps);
 
   // gd = dz * gamma: short strips keep it in fp32 registers for the second sweep (the SiLU derivative costs an exp and a
   // reciprocal per element); for the long ones that would double the footprint, so they recompute it
