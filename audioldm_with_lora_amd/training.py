@@ -17,6 +17,7 @@ All LoRA parameters live in one flat fp32 buffer (the nn.Parameters are views in
 launch per step refreshes every packed bf16 operand.
 """
 import math
+import os
 import struct
 from types import SimpleNamespace
 
@@ -370,6 +371,9 @@ def trainer_of(unet, create=True):
     return tr
 
 
+SIDE_STREAM_H2D = os.environ.get("ALDM_NO_SIDE_STREAM_H2D") is None      # step_from_batch: batch copies on a side stream (A/B aid)
+
+
 class LoraTrainer:
     """One process per GPU; `world`/`rank` follow torch.distributed when it is initialised (RCCL over xGMI)."""
 
@@ -662,9 +666,25 @@ class LoraTrainer:
         ids, mask = batch["input_ids"].squeeze(1), batch["attention_mask"].squeeze(1)
         lens = text_encoder._lengths(ids, mask)                  # host-side validation of the padding mask (CPU tensors)
         Le = min(ids.shape[1], (int(lens.max()) + 63) // 64 * 64)   # 64-token buckets: few distinct graphs
-        args = (batch["log_mel_spec"].to(dev, torch.float32).contiguous(), ids[:, :Le].to(dev, torch.int64).contiguous(),
-                lens.to(dev), sample_noise.to(dev, torch.float32).contiguous(), noise.to(dev, torch.float32).contiguous(),
-                timesteps.to(dev, torch.int64).contiguous())
+        # Host -> device on a SIDE stream: a pageable `.to(device)` blocks the host until the copy has run, and on the step's own stream
+        # that means until the PREVIOUS step's graph has finished -- the host-side work of a step (~0.3 ms: slicing, six copies, the
+        # replay call) then sits between two graphs instead of under the first.  The side stream is idle, so the host only waits for
+        # the copies themselves; the step's stream picks the staged tensors up behind an event.
+        if SIDE_STREAM_H2D:
+            if getattr(self, "_h2d_stream", None) is None:
+                self._h2d_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(self._h2d_stream):
+                args = (batch["log_mel_spec"].to(dev, torch.float32).contiguous(), ids[:, :Le].to(dev, torch.int64).contiguous(),
+                        lens.to(dev), sample_noise.to(dev, torch.float32).contiguous(), noise.to(dev, torch.float32).contiguous(),
+                        timesteps.to(dev, torch.int64).contiguous())
+            main.wait_stream(self._h2d_stream)
+            for a in args:
+                a.record_stream(main)
+        else:
+            args = (batch["log_mel_spec"].to(dev, torch.float32).contiguous(), ids[:, :Le].to(dev, torch.int64).contiguous(),
+                    lens.to(dev), sample_noise.to(dev, torch.float32).contiguous(), noise.to(dev, torch.float32).contiguous(),
+                    timesteps.to(dev, torch.int64).contiguous())
         sf = float(vae.config.scaling_factor)
 
         def body(mel, ids_d, kv_len, eps, nz, ts):
