@@ -52,6 +52,7 @@ class IgemmArgs(C.Structure):
         ("gnin_gamma", C.c_void_p), ("gnin_beta", C.c_void_p), ("gnin_q1", C.c_void_p), ("gnin_q2", C.c_void_p),
         ("gnin_bm1", C.c_int), ("gnin_tpi1", C.c_int), ("gnin_bm2", C.c_int), ("gnin_tpi2", C.c_int),
         ("gnin_groups", C.c_int), ("gnin_act", C.c_int), ("gnin_eps", C.c_float),
+        ("xcd_map", C.c_int),
     ]
 
 

@@ -44,7 +44,7 @@ struct AttnCfg {
   // VL: the row sum l = sum_k p is accumulated by VALU adds instead of the row of ones.  Where DP is a multiple of 32 (d = 32, 64) the
   // ones row needs a d-tile of its own -- 4 of the 12 MFMAs per 64-key tile at d = 32 -- and, MFMA and VALU time being additive on this
   // chip (see the header), 32 adds (64-128 cycles) are cheaper than 4 MFMAs (128 cycles) plus their 4 fragment reads.
-  static constexpr bool VL = DP % 32 == 0;
+  static constexpr bool VL = DP % 32 == 0;                 // (round 4: these sizes sum l on the matrix pipe after all, see ML below)
   static constexpr int DT = VL ? DP / 32 : DP / 32 + 1;    // 32-row d-tiles of O^T, INCLUDING (unless VL) the row of ones at row DP
   static constexpr int ONES_T = VL ? 0 : DP / 32;          // tile / accumulator register that holds l = sum p (lanes hh = 0)
   static constexpr int ONES_I = 4 * ((DP % 32) >> 3);
@@ -228,7 +228,18 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float m_run = 0.f;                            // running maximum of the SCALED scores (log2 domain); set by the first tile
-  float l_run = 0.f;                            // VL: this lane's share of l (its 32 keys of every tile)
+  // ML (d = 32, 64): l = sum_k p on the matrix pipe without a row of ones in LDS -- one more MFMA per 16 keys whose A operand is a
+  // REGISTER CONSTANT of ones, so every row of `lacc` is the query column's sum of the SAME bf16-rounded P that multiplies V.  Round 3
+  // summed l with 16 v_pk_add_f32 per tile on the grounds that MFMA and VALU time add up; tools/micro/mfma_valu_gap.hip (instruction
+  // stream pinned by inline asm) shows they do not: an MFMA costs its wave 8 issue cycles, its 32 pipe cycles run under the next five
+  // VALU instructions (and under the SIMD's other wave), and this loop is VALU-issue-bound -- 4 x 8 issue cycles replace 16 packed adds.
+  f32x16 lacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+  const bf16x8 ones8 = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+  f32x16 minit;                                 // C operand of every tile's first S^T MFMA: -m_run (PRESCALED), else zeros
+#pragma unroll
+  for (int i = 0; i < 16; ++i) minit[i] = 0.f;
 
   const int ntiles = (Nk + KV - 1) / KV;
   const int niter = (ntiles + SP - 1) / SP;
@@ -238,15 +249,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // ---- S' = K Q^T (- m_run as the initial accumulator when the scores come out of the MFMA already scaled) ----
   auto scores = [&](int it, f32x16 (&s)[2]) {
     const int buf = (it & 1) * SP + grp;
-    const float acc0 = PRESCALED ? -m_run : 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[sub][i] = acc0;
-#pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + buf * Cfg::KBYTES + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+        // the first K-step reads its C operand from `minit` (-m_run in every row; zeros for unscaled scores) and writes a DIFFERENT
+        // register block: no 16 v_mov per 32 keys to seed the accumulator
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? minit : s[sub], 0, 0, 0);
       }
     }
   };
@@ -286,30 +296,34 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         for (int t = 0; t < DT; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) o[t][i] *= alpha;                // includes l (row DP)
-        if constexpr (Cfg::VL) l_run *= alpha;
+        if constexpr (Cfg::VL) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
+        }
       }
       if (PRESCALED) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
           for (int i = 0; i < 16; ++i) s[sub][i] -= delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) minit[i] = -m_run;
       }
     }
     bf16x8 pf[4];
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    f32x2_t lp[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};        // (pairs: v_pk_add_f32, 16 adds per tile instead of 32)
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
         const float e0 = PRESCALED ? s[sub][i] : fmaf(s[sub][i], c, -m_run);
         const float e1 = PRESCALED ? s[sub][i + 1] : fmaf(s[sub][i + 1], c, -m_run);
-        const f32x2_t pe = {__builtin_amdgcn_exp2f(e0), __builtin_amdgcn_exp2f(e1)};
-        if constexpr (Cfg::VL) lp[(i >> 1) & 1] += pe;
-        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)pe[0];
-        pf[sub * 2 + (i >> 3)][(i & 7) + 1] = (bf16)pe[1];
+        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)__builtin_amdgcn_exp2f(e0);
+        pf[sub * 2 + (i >> 3)][(i & 7) + 1] = (bf16)__builtin_amdgcn_exp2f(e1);
       }
-    if constexpr (Cfg::VL) l_run += (lp[0][0] + lp[0][1]) + (lp[1][0] + lp[1][1]);
+    if constexpr (Cfg::VL) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[s2], lacc, 0, 0, 0);
+    }
     // ---- O^T += V^T P^T (row DP of V^T is ones: l accumulates alongside) ----
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mine[(1 + t * 16 + i) * 64 + lane] = o[t][i];
-      mine[(1 + DT * 16) * 64 + lane] = l_run;
+      mine[(1 + DT * 16) * 64 + lane] = lacc[0];
     }
     __syncthreads();
     if (grp > 0) return;
@@ -381,14 +395,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * a0 + peer[(1 + t * 16 + i) * 64 + lane] * a1;   // l (row DP) merges like any row
-      l_run = l_run * a0 + peer[(1 + DT * 16) * 64 + lane] * a1;
+      lacc[0] = lacc[0] * a0 + peer[(1 + DT * 16) * 64 + lane] * a1;
     }
   }
 
   // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
   // l sits in O^T row DP: register ONES_I of tile ONES_T on the hh = 0 lanes (the hh = 1 lanes hold row DP + 4 there: zero padding)
-  const float l_half = Cfg::VL ? l_run : o[Cfg::ONES_T][Cfg::ONES_I];   // (VL: this lane's 32 keys per tile; the other 32 sit in lane ^ 32)
-  const float l_tot = l_half + __shfl_xor(l_half, 32, 64);
+  // (VL: every row of lacc holds the whole sum for this lane's query column -- all 64 keys of every tile went through the MFMA's k)
+  const float l_half = o[Cfg::ONES_T][Cfg::ONES_I];
+  const float l_tot = Cfg::VL ? lacc[0] : l_half + __shfl_xor(l_half, 32, 64);
   const float inv = 1.0f / l_tot;
   if (lse && hh == 0 && q0 + r < N)   // log2-domain log-sum-exp of the scaled scores: p = exp2(s*c - lse)
     lse[((long long)b * gridDim.y + head) * N + q0 + r] = m_run + __log2f(l_tot);
@@ -439,6 +454,9 @@ int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt
   if (force == 41) return launch_attn<DP, 4, 1, PS>(ALDM_ATTN_ARGS);
   if (force == 42) return launch_attn<DP, 4, 2, PS>(ALDM_ATTN_ARGS);
   if (force == 21) return launch_attn<DP, 2, 1, PS>(ALDM_ATTN_ARGS);
+  if constexpr (DP == 32) {
+    if (force == 162) return launch_attn<DP, 16, 2, PS>(ALDM_ATTN_ARGS);   // 16 waves = 4 per SIMD, keys split over two wave groups
+  }
   if (N >= 768) {
     if ((long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8, 1, PS>(ALDM_ATTN_ARGS);
     return launch_attn<DP, 8, 2, PS>(ALDM_ATTN_ARGS);

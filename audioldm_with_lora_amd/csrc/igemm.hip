@@ -101,7 +101,14 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   if (d.splits > d.nkt) d.splits = d.nkt;
   d.kt_per_split = cdiv(d.nkt, d.splits);
   d.splits = cdiv(d.nkt, d.kt_per_split);
-  d.tiles_n = 0;
+  d.tiles_n = 0; d.tiles_m = 0; d.nwg = 0;
+  ALDM_CHECK_ARG(p->xcd_map >= 0 && p->xcd_map <= 2, "igemm: xcd_map must be 0 (auto), 1 (activation-stationary) or 2 (weight-stationary)");
+  {
+    // which operand an XCD's L2 keeps (igemm_work_item): the one that would otherwise be streamed by all eight L2s is the larger one
+    const unsigned long long act = 2ull * p->B * p->IH * p->IW * Ctot + 2ull * p->B * p->OH * p->OW * Cext;
+    const unsigned long long wgt = 2ull * p->Cout * p->Kpad;
+    d.xmap = p->xcd_map ? p->xcd_map - 1 : (wgt > act ? 1 : 0);
+  }
   {
     const unsigned long long xb = 2ull * p->B * p->IH * p->IW * p->Cin, x2b = 2ull * p->B * p->IH * p->IW * p->Cin2;
     const unsigned long long wb = 2ull * p->Cout * p->Kpad, lb = 2ull * p->Rp * p->Kpad;

@@ -56,6 +56,8 @@ struct IgemmDev {
   int vt_col0, vt_ld; long long vt_bs; int vt_dual;
   int splits, kt_per_split, nkt;
   int tiles_n;
+  int tiles_m, nwg, xmap;     // 1-D grid of tiles_m * tiles_n * splits workgroups; xmap: work item -> XCD order (see igemm_work_item)
+  FastDiv fd_tiles_m, fd_splits;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
   unsigned long long* diag;   // diagnostic builds only
   FastDiv fd_ohw, fd_ow, fd_halo;   // fd_halo: / (OW + 2), halo kernel only
@@ -72,6 +74,34 @@ struct IgemmDev {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ---- work item of a workgroup -----------------------------------------------------------------
+// The grid is ONE-dimensional (tiles_m * tiles_n * splits workgroups): the hardware deals workgroups round-robin over the 8 XCDs by
+// their LINEAR id (blocks b, b + 8, ... share an L2), so a 3-D grid's `blockIdx.x & 7` is the XCD only when gridDim.x % 8 == 0.
+// Each XCD gets a CONTIGUOUS range of the launch's work items in one of two orders, chosen per launch on the host:
+//   xmap 0 -- activation-stationary: (tile_m, tile_n) slowest, split fastest.  An XCD owns a band of output rows for every N-tile and
+//             every K-split: its slice of the activation image (plus halo) stays in its 4 MiB L2, every L2 streams the whole weight
+//             matrix.  Right where activations >> weights (the 4000- / 1000-pixel levels, VAE, vocoder).
+//   xmap 1 -- weight-stationary: (split, tile_n) slowest, tile_m fastest.  An XCD owns a (K-slice, N-tile) range of the WEIGHTS for all
+//             rows: each weight byte is fetched by one L2 instead of eight.  Right where weights >> activations (the 252- / 64-token
+//             levels: 7.4 MB of weights against 0.65 MB of activations at M = 512 -- round 3 measured 45 MB fetched per launch).
+// Bijective for any grid size; affects speed only.
+__device__ __forceinline__ void igemm_work_item(const IgemmDev& p, int& tile_m, int& tile_n, int& split) {
+  const int nwg = p.nwg, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  if (p.xmap) {
+    const int sn = fdiv(w, p.fd_tiles_m);
+    tile_m = w - sn * p.tiles_m;
+    split = fdiv(sn, p.fd_tiles_n);
+    tile_n = sn - split * p.tiles_n;
+  } else {
+    const int t = fdiv(w, p.fd_splits);
+    split = w - t * p.splits;
+    tile_m = fdiv(t, p.fd_tiles_n);
+    tile_n = t - tile_m * p.tiles_n;
+  }
+}
 
 // ---- epilogue helpers -------------------------------------------------------------------------
 // v[0..3] are 4 consecutive output columns n..n+3 of output row m, bias etc. already added.
@@ -636,9 +666,9 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(const IgemmDev p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = fdiv(blockIdx.x, p.fd_tiles_n), tile_n = blockIdx.x - tile_m * p.tiles_n;
+  int tile_m, tile_n, split;
+  igemm_work_item(p, tile_m, tile_n, split);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.z;
   const int kt0 = split * p.kt_per_split;
   const int kt1 = min(p.nkt, kt0 + p.kt_per_split);
 
@@ -889,18 +919,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  // XCD-aware tile order: hardware deals workgroups round-robin over the 8 XCDs (blocks b, b+8, ... share an L2), so
-  // give each XCD a CONTIGUOUS range of output tiles -- its slice of the activation image (plus halo) then stays in
-  // that XCD's 4 MiB L2 instead of every L2 streaming the whole image.  Bijective for any grid size; speed only.
-  int wgid;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_m = fdiv(wgid, p.fd_tiles_n), tile_n = wgid - tile_m * p.tiles_n;
+  int tile_m, tile_n, split;                    // XCD-aware work-item order (igemm_work_item)
+  igemm_work_item(p, tile_m, tile_n, split);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.z;
   const int kt0 = split * p.kt_per_split;
   const int kt1 = min(p.nkt, kt0 + p.kt_per_split);
 
@@ -1220,7 +1241,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_pipe_kernel(const IgemmDev
 #ifdef ALDM_DIAG
   if (p.diag && lane == 0) {
     unsigned long long dg_t_end; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t_end) :: "memory");
-    unsigned long long* o = p.diag + ((long long)(blockIdx.x + gridDim.x * blockIdx.z) * 4 + wave) * 8;
+    unsigned long long* o = p.diag + ((long long)blockIdx.x * 4 + wave) * 8;
     o[0] = dg_wait; o[1] = dg_bar; o[2] = dg_issue; o[3] = dg_mma;
     o[4] = dg_t_loop_end - dg_t_entry - (dg_wait + dg_bar + dg_issue + dg_mma);   // prologue (everything before / around the loop)
     o[5] = dg_t_end - dg_t_loop_end;                                               // LoRA tail + epilogue incl. store drain
@@ -1316,7 +1337,11 @@ int launch_cfg(const IgemmDev& d, hipStream_t st) {
   IgemmDev dd = d;
   dd.tiles_n = cdiv(d.N, BN);
   dd.fd_tiles_n = make_fastdiv((unsigned)dd.tiles_n);
-  dim3 grid(cdiv(d.M, BM) * dd.tiles_n, 1, d.splits);
+  dd.tiles_m = cdiv(d.M, BM);
+  dd.fd_tiles_m = make_fastdiv((unsigned)dd.tiles_m);
+  dd.fd_splits = make_fastdiv((unsigned)d.splits);
+  dd.nwg = dd.tiles_m * dd.tiles_n * d.splits;
+  dim3 grid(dd.nwg, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(S == 0 ? THREADS : 64 * WM * WN), lds, st, dd);
   return aldm_launch_status("igemm");
 }

@@ -386,6 +386,11 @@ class QStats:
 QSTATS_MIN_HW = 2048
 
 
+# aldm_igemm_t.xcd_map: 0 = the library decides per launch which operand an XCD's L2 keeps (weight-stationary where the weight matrix
+# is the larger operand), 1 / 2 force activation- / weight-stationary (A/B measurements only).
+XCD_MAP = int(os.environ.get("ALDM_XCD_MAP", "0"))
+
+
 class Deferred:
     """A split-K convolution whose reduce is still pending (conv(..., defer=True)): the fp32 partial tiles sit in the shared
     workspace, `out` is the bf16 tensor the consumer will fill.  The ONLY valid consumer is the next groupnorm() call on this
@@ -643,6 +648,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         a.workspace = _workspace(splits * M * pw.N * 4, x.device).data_ptr()
     a.tile = tile
     a.ring = ring
+    a.xcd_map = XCD_MAP
     lib = _lib.load()
     eff = lib.aldm_igemm_effective_splits(C.byref(a)) if (gn_defer and splits > 1) else 1
     a.defer_reduce = 1 if eff > 1 else 0
@@ -1194,6 +1200,7 @@ class TnBatch:
         self.jobs = {32: [], 64: []}
         self.keep = []               # operand tensors stay referenced until the launch is recorded
         self._packed = {}
+        self.owner = None            # the snapshot whose records the device tables currently hold (None: an eager launch's)
 
     def add(self, P, Q, rows_dev, Qc):
         M, Rp = P.shape
@@ -1223,6 +1230,21 @@ class TnBatch:
         """Copy the packed tables to the device (outside any capture)."""
         for rp, (blob, n, _) in self._packed.items():
             self.tab[rp][: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        self.owner = None
+
+    def snapshot(self):
+        """The records of the launch just recorded (call right after a capture ends): a captured graph replays aldm_tn_batched
+        against the ONE device table, so it must be able to put ITS records back (restore) after anything else used the table."""
+        return {rp: blob for rp, (blob, _, _) in self._packed.items()}
+
+    def restore(self, snap):
+        """Make the device tables hold `snap`'s records (no-op when they already do).  Stream-ordered H2D copies on the current
+        stream, i.e. in front of the replay that needs them."""
+        if snap is None or self.owner is snap:
+            return
+        for rp, blob in snap.items():
+            self.tab[rp][: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        self.owner = snap
 
     def launch(self):
         self._pack()

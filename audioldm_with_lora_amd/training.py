@@ -362,12 +362,8 @@ def trainer_of(unet, create=True):
             tr.step_count = old.step_count
         else:
             tr = LoraTrainer(unet, None, use_graph=False)
-    elif tr is not None and tr.weights_version != unet._weights_version:
-        # the FROZEN weights may have changed in place (load_state_dict of the base, a no-op .to()): the LoRA views are intact,
-        # but the engine's packed copies of the base weights (plan + LoraSite operands) are stale
-        tr._build_sites()
-        tr.graph, tr._static, tr._eager_steps = None, None, 0
-        tr.weights_version = unet._weights_version
+    elif tr is not None:
+        tr._ensure_fresh()
     return tr
 
 
@@ -391,6 +387,7 @@ class LoraTrainer:
         self.flat = FlatLora(unet, self.dev)
         self.flat.on_change = unet.invalidate_packed         # an optimiser update makes the UNet's inference plan stale
         self.use_graph, self.graph, self._static, self._eager_steps = use_graph, None, None, 0
+        self._graph_tab, self._body_graphs, self._body_eager = None, {}, {}
         self.ac_dev = scheduler.alphas_cumprod.to(self.dev, torch.float32) if scheduler is not None else None
         self._tape = None
         self._build_sites()
@@ -434,6 +431,20 @@ class LoraTrainer:
 
     def repack(self):
         ops.lora_pack(self.jobs_dev, self.njobs)
+
+    def _ensure_fresh(self):
+        """The FROZEN weights may have changed in place under a live engine (load_state_dict of the base, `.to()`): the LoRA views are
+        intact, but the packed copies of the base weights (plan + LoraSite operands) are stale, and every captured graph holds pointers
+        into the operands `_build_sites` is about to free.  Rebuild the sites and drop EVERY graph (step's and step_from_batch's) and
+        their warm-up counters.  Called at the top of every entry point that launches, and by trainer_of."""
+        if self.weights_version == self.unet._weights_version:
+            return
+        self._build_sites()
+        self.graph, self._static, self._eager_steps = None, None, 0
+        self._graph_tab = None
+        self._body_graphs, self._body_eager = {}, {}
+        self.tnb.owner = None
+        self.weights_version = self.unet._weights_version
 
     # ---- forward with tape ----
     def _attention(self, tape, tblk_attn, Pa, hn, h_res, B, N):
@@ -565,6 +576,7 @@ class LoraTrainer:
 
     # ---- autograd-shaped boundary (the reference's own loop body drives these through unet(...) / loss.backward()) ----
     def _taped_forward(self, sample, timestep, class_labels):
+        self._ensure_fresh()
         f = self.flat
         b = sample.shape[0]
         self.repack()
@@ -632,6 +644,7 @@ class LoraTrainer:
         """Fills the flat gradient buffer (this rank's batch-mean loss in the last slot); returns that loss slot.
         After two eager warm-up steps the whole launch sequence (~1000 kernels) is captured once into a hipGraph and
         replayed from static input buffers -- the eager step is host-launch-bound."""
+        self._ensure_fresh()
         f = self.flat
         args = self._to_dev(latents, noise, timesteps, prompt_embeds)
         if not self.use_graph:
@@ -640,6 +653,7 @@ class LoraTrainer:
         if self.graph is not None and all(a.shape == b.shape for a, b in zip(args, self._static)):
             for dst, src in zip(self._static, args):
                 dst.copy_(src)
+            self.tnb.restore(self._graph_tab)                  # the job table of THIS graph's addresses, if anything overwrote it
             self.graph.replay()
             return f.grads[f.n:]
         self._eager_steps += 1
@@ -651,7 +665,8 @@ class LoraTrainer:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
             self._fwd_bwd(*self._static)
-        self.tnb.upload()                                        # job table of the captured addresses (H2D copies cannot be captured)
+        self._graph_tab = self.tnb.snapshot()                    # job table of the captured addresses (H2D copies cannot be captured)
+        self.tnb.restore(self._graph_tab)
         self.graph.replay()
         return f.grads[f.n:]
 
@@ -662,6 +677,7 @@ class LoraTrainer:
             noisy = add_noise(latents, noise, timesteps);  pred = unet(noisy, t, class_labels=prompt_embeds);  mse;  backward
         as ONE captured hipGraph per (batch shape, caption-length bucket), then the flat all-reduce and AdamW as in step().
         sample_noise [B, 8, H/4, 16] is the N(0, 1) draw of latent_dist.sample() (passed in so that the graph has no RNG state)."""
+        self._ensure_fresh()
         dev = self.dev
         ids, mask = batch["input_ids"].squeeze(1), batch["attention_mask"].squeeze(1)
         lens = text_encoder._lengths(ids, mask)                  # host-side validation of the padding mask (CPU tensors)
@@ -698,8 +714,6 @@ class LoraTrainer:
         if not self.use_graph:
             body(*args)
         else:
-            if not hasattr(self, "_body_graphs"):
-                self._body_graphs, self._body_eager = {}, {}
             ent = self._body_graphs.get(key)
             if ent is None:
                 n = self._body_eager.get(key, 0) + 1
@@ -712,13 +726,17 @@ class LoraTrainer:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         body(*static)
-                    self.tnb.upload()
-                    self._body_graphs[key] = (g, static)
+                    # every graph's aldm_tn_batched launch reads the trainer's ONE device job table: each graph keeps the table of ITS
+                    # captured addresses and puts it back before a replay whenever another graph, a capture or an eager step overwrote it
+                    tab = self.tnb.snapshot()
+                    self._body_graphs[key] = (g, static, tab)
+                    self.tnb.restore(tab)
                     g.replay()
             else:
-                g, static = ent
+                g, static, tab = ent
                 for dst, src in zip(static, args):
                     dst.copy_(src)
+                self.tnb.restore(tab)
                 g.replay()
         return self._apply_update(f.grads[f.n:])
 

@@ -70,44 +70,53 @@ def launch_rows(engine):
     return [(label, flops, nbytes, s.elapsed_time(e) * 1e3, site) for label, flops, nbytes, s, e, site in rows]
 
 
-def trace_replays(engine, reps=6):
-    """Device timestamps of every kernel of `reps` graph replays (kineto / roctracer).  Returns (kernels per replay as
-    [(name, avg duration us)], avg wall span of one replay in us) or (None, None) when the tracer is unavailable."""
+def trace_steps(step_fn, end_marker, start_marker=None, reps=6):
+    """Device timestamps of every kernel of `reps` calls of step_fn (kineto / roctracer), cut into steps at the kernel whose name
+    contains end_marker (the step's LAST launch; start_marker = its first, used when no end marker shows up).  Only COMPLETE steps
+    with identical kernel sequences are kept -- the tracer may drop or add events at the edges of its window, so dividing totals by
+    `reps` is wrong.  Returns (kernels per step as [(name, avg duration us)], avg wall span of one step in us, steps kept) or
+    (None, None, 0) when the tracer is unavailable."""
     try:
         from torch.profiler import ProfilerActivity, profile
-        engine.step()
+        step_fn()
         torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for _ in range(reps):
-                engine.step()
+                step_fn()
             torch.cuda.synchronize()
         evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name and "Memset" not in e.name]
         evs.sort(key=lambda e: e.time_range.start)
-        # cut the stream into replays at the step's first kernel (gather_row); keep the complete ones (the tracer may drop or add
-        # a few events at the edges of its window)
-        # (the step's LAST kernel is the fused guidance / DDIM / counter launch; with several chains the step still opens with gather_row)
-        ends = [i for i, e in enumerate(evs) if "ddim_step_fused_kernel" in e.name]
+        ends = [i for i, e in enumerate(evs) if end_marker in e.name]
         if ends:
             starts = [0] + [i + 1 for i in ends[:-1]]
             segs = [evs[a:b + 1] for a, b in zip(starts, ends)][1:]      # the first segment may be cut by the tracer's window
-        else:
-            starts = [i for i, e in enumerate(evs) if "gather_row_kernel" in e.name]
+        elif start_marker:
+            starts = [i for i, e in enumerate(evs) if start_marker in e.name]
             segs = [evs[a:b] for a, b in zip(starts, starts[1:] + [len(evs)])]
+        else:
+            segs = []
         if not segs:
-            print(f"[bench] kernel trace: no replay boundary among {len(evs)} device events", file=sys.stderr)
-            return None, None
+            print(f"[bench] kernel trace: no step boundary among {len(evs)} device events", file=sys.stderr)
+            return None, None, 0
         lens = sorted(len(g) for g in segs)
         n = lens[len(lens) // 2]
         segs = [g for g in segs if len(g) == n and [e.name for e in g] == [e.name for e in segs[[len(x) for x in segs].index(n)]]]
         if len(segs) < 2:
-            print(f"[bench] kernel trace: replays do not line up ({lens})", file=sys.stderr)
-            return None, None
+            print(f"[bench] kernel trace: steps do not line up ({lens})", file=sys.stderr)
+            return None, None, 0
         per = [(segs[0][i].name, sum(g[i].time_range.elapsed_us() for g in segs) / len(segs)) for i in range(n)]
         span = sum(g[-1].time_range.end - g[0].time_range.start for g in segs) / len(segs)
-        return per, span
+        return per, span, len(segs)
     except Exception as ex:                                  # measurement aid only: never let it take the bench line down
         print(f"[bench] kernel trace unavailable: {type(ex).__name__}: {ex}", file=sys.stderr)
-        return None, None
+        return None, None, 0
+
+
+def trace_replays(engine, reps=6):
+    """One denoise step's kernels from replayed graphs: the step's LAST kernel is the fused guidance / DDIM / counter launch; with
+    several chains it still opens with gather_row."""
+    per, span, _ = trace_steps(engine.step, "ddim_step_fused_kernel", "gather_row_kernel", reps)
+    return per, span
 
 
 def launch_floor_us(n=200, full_grid=False):
@@ -330,7 +339,26 @@ def bench_pipeline(unet, batch, seconds, nsteps, guidance, seed_off=0):
     return min(times), first, legs
 
 
-def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
+TRAIN_FAMILIES = (("attention_bwd", ("attn_bwd",)), ("attention_fwd", ("attention_kernel", "attn_block64")),
+                  ("gemm_lora_site", ("igemm_pipe_kernel<64, 64, 2, 2, 32", "igemm_pipe_kernel<128, 64, 2, 2, 32", "igemm_pipe_kernel<64, 128, 2, 2, 32",
+                                      "igemm_pipe_kernel<128, 128, 2, 2, 32", "igemm_pipe_kernel<64, 64, 2, 2, 64", "igemm_pipe_kernel<128, 64, 2, 2, 64",
+                                      "igemm_pipe_kernel<64, 128, 2, 2, 64", "igemm_pipe_kernel<128, 128, 2, 2, 64", "pgemm_kernel")),
+                  ("gemm", ("igemm_pipe_kernel", "igemm_kernel", "igemm_halo_kernel")), ("splitk_reduce", ("igemm_reduce",)),
+                  ("groupnorm_bwd", ("groupnorm_bwd",)), ("groupnorm_fwd", ("groupnorm", "gn_silu")),
+                  ("layernorm_geglu", ("layernorm", "geglu")), ("lora_grad", ("tn_mfma", "tn_small", "lora_pack")),
+                  ("transpose", ("transpose_tokens",)), ("optimizer", ("adamw",)))
+
+
+def train_families(per):
+    """ms per step by kernel family (first matching entry of TRAIN_FAMILIES; everything else -> other)."""
+    out = {}
+    for name, us in per:
+        fam = next((f for f, keys in TRAIN_FAMILIES if any(k in name for k in keys)), "other")
+        out[fam] = out.get(fam, 0.0) + us / 1e3
+    return {k: round(v, 3) for k, v in sorted(out.items(), key=lambda kv: -kv[1])}
+
+
+def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8, trace=False):
     """Config 3/4: LoRA fine-tune step (add_noise -> UNet fwd -> MSE -> bwd -> flat all-reduce -> AdamW) on synthetic
     10.24 s mel latents [8, 8, 256, 16] per GPU; clips/s = world * batch / step time."""
     from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model
@@ -366,11 +394,18 @@ def bench_train(world, rank, steps=8, warmup=3, batch=8, rank_lora=8):
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
     final = float(loss)
+    extra = {}
+    if trace and rank == 0:
+        # the step's kernels from complete replays only (its last launch is the flat AdamW); families by symbol
+        per, span, kept = trace_steps(lambda: tr.step(lat, noise, t, emb), "adamw_flat", reps=5)
+        if per:
+            extra = {"launches_per_step_total": len(per), "kernel_time_sum_ms": round(sum(u for _, u in per) / 1e3, 3),
+                     "graph_span_ms": round(span / 1e3, 3), "trace_steps_kept": kept, "families_ms": train_families(per)}
     del tr, unet
     torch.cuda.empty_cache()
     return {"metric": "lora_train_clips_per_sec", "value": round(world * batch * steps / dt, 3), "unit": "10.24s-clips/s",
             "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "per_gpu_batch": batch, "lora_rank": rank_lora,
-            "lora_params": 112640 * rank_lora, "final_loss": round(final, 5),
+            "lora_params": 112640 * rank_lora, "final_loss": round(final, 5), **extra,
             "collective": "1 flat fp32 all-reduce/step (RCCL)" if world > 1 else "none",
             "dtype": TRAIN_DTYPE, "gradient_tolerance": TRAIN_TOL}
 
@@ -553,7 +588,7 @@ def main():
         torch.cuda.empty_cache()
         # config 3 (rank 8) on one GPU, config 4 (rank 16, one flat all-reduce per step) data-parallel; on one GPU a short
         # rank-16 leg also runs so that config 4's per-GPU path (the Rp = 64 kernels) is exercised before any N > 1 run
-        train = bench_train(world, rank, rank_lora=(8 if world == 1 else 16))
+        train = bench_train(world, rank, rank_lora=(8 if world == 1 else 16), trace=not args.no_trace)
         if world == 1:
             train16 = bench_train(world, rank, steps=4, warmup=3, rank_lora=16)
             body_leg = bench_loop_body()

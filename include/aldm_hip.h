@@ -123,6 +123,12 @@ typedef struct {
      normalised tensor through HBM.  gnin_gamma / gnin_beta have Cin + Cin2 entries.  NULL gnin_gamma = off. */
   const float* gnin_gamma; const float* gnin_beta; const float* gnin_q1; const float* gnin_q2;
   int gnin_bm1, gnin_tpi1, gnin_bm2, gnin_tpi2, gnin_groups, gnin_act; float gnin_eps;
+  /* Which operand each of the 8 XCDs' (non-coherent, 4 MiB) L2s keeps.  The workgroups of a launch are dealt round-robin over the XCDs;
+     the kernel hands each XCD a contiguous range of (M-tile, N-tile, K-split) work items.  1 = activation-stationary (an XCD owns a band
+     of output rows: right when activations >> weights), 2 = weight-stationary (an XCD owns a (K-slice, N-tile) range of the weights for
+     every row: right at the UNet's 252- / 64-token levels, where every L2 would otherwise stream the whole weight matrix),
+     0 = auto: weight-stationary iff the weight matrix is larger than the activation image.  Speed only; results are identical. */
+  int xcd_map;
 } aldm_igemm_t;
 
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,

@@ -113,3 +113,60 @@ def test_whole_loop_body_as_one_graph_equals_encoders_then_step():
         assert abs(x - y) < 1e-3 * abs(y) + 1e-6, (la, lb)
     pa, pb = tr_a.flat.params, tr_b.flat.params
     assert float((pa - pb).norm() / pb.norm()) < 1e-3
+
+
+def test_two_graph_keys_share_one_job_table_and_survive_a_weight_reload():
+    """step_from_batch keeps one captured hipGraph per batch shape, and every graph's aldm_tn_batched launch reads the trainer's ONE
+    device job table (LoRA-gradient products [REF script/train/train_audioldm_lora.py:557-565]).  Alternate two batch shapes (a full
+    batch and the short last batch of an epoch) so that replays of one graph follow captures / eager warm-up steps of the other: every
+    loss and the final adapter must equal the eager (use_graph=False) trainer's.  Then reload the frozen base weights in place: the
+    engine must drop every graph (they point at freed packed operands) and keep training correctly."""
+    from audioldm_with_lora_amd import configs
+    from audioldm_with_lora_amd.clap_text import ClapTextModelWithProjection
+    from audioldm_with_lora_amd.lora import LoraConfig, get_peft_model
+    from audioldm_with_lora_amd.scheduler import DDIMScheduler
+    from audioldm_with_lora_amd.script.train import synthetic_batch
+    from audioldm_with_lora_amd.training import LoraTrainer
+    from audioldm_with_lora_amd.unet import UNet2DConditionModel
+    from audioldm_with_lora_amd.vae import AutoencoderKL
+
+    def build(use_graph):
+        torch.manual_seed(13)
+        unet = UNet2DConditionModel(**configs.tiny_unet())
+        unet.requires_grad_(False)
+        get_peft_model(unet, LoraConfig(r=2, lora_alpha=2, target_modules=["to_q", "to_k", "to_v", "to_out.0"], init_lora_weights="gaussian"))
+        vae = AutoencoderKL(**configs.tiny_vae()).requires_grad_(False).cuda()
+        clap = ClapTextModelWithProjection(**dict(configs.tiny_clap_text(), max_position_embeddings=514, projection_dim=64)).requires_grad_(False).cuda()
+        return LoraTrainer(unet.cuda(), DDIMScheduler(), lr=1e-3, max_train_steps=40, use_graph=use_graph), vae, clap
+
+    g = torch.Generator().manual_seed(3)
+
+    def make(bs):
+        b = synthetic_batch(bs, g, vocab=200)
+        b["log_mel_spec"] = b["log_mel_spec"][:, :, :64].contiguous()
+        return (b, torch.randn(bs, 8, 16, 16, generator=g), torch.randint(0, 1000, (bs,), generator=g), torch.randn(bs, 8, 16, 16, generator=g))
+
+    # A A A(capture) | B B (eager warm-up of the other key overwrites the table) | A (replay) | B (capture) | A B A B (replays)
+    order = [2, 2, 2, 1, 1, 2, 1, 2, 1, 2, 1]
+    steps = [make(bs) for bs in order]
+    tr_g, vae_g, clap_g = build(True)
+    tr_e, vae_e, clap_e = build(False)
+    lg = [float(tr_g.step_from_batch(vae_g, clap_g, *s)) for s in steps]
+    le = [float(tr_e.step_from_batch(vae_e, clap_e, *s)) for s in steps]
+    assert len(tr_g._body_graphs) == 2
+    for i, (x, y) in enumerate(zip(lg, le)):
+        assert abs(x - y) < 2e-3 * abs(y) + 1e-6, (i, lg, le)
+    rel = float((tr_g.flat.params - tr_e.flat.params).norm() / tr_e.flat.params.norm())
+    print(f"two-key graph vs eager: adapter rel L2 {rel:.3e}")
+    assert rel < 2e-3
+
+    # the frozen base reloaded in place (same values, new storage generation): every graph goes, the next steps re-warm and re-capture
+    for tr in (tr_g, tr_e):
+        base = {k: v.clone() for k, v in tr.unet.state_dict().items() if "lora_" not in k}
+        tr.unet.load_state_dict(base, strict=False)
+    more = [make(2) for _ in range(4)]
+    lg2 = [float(tr_g.step_from_batch(vae_g, clap_g, *s)) for s in more]
+    assert len(tr_g._body_graphs) == 1 and tr_g.weights_version == tr_g.unet._weights_version
+    le2 = [float(tr_e.step_from_batch(vae_e, clap_e, *s)) for s in more]
+    for x, y in zip(lg2, le2):
+        assert abs(x - y) < 2e-3 * abs(y) + 1e-6, (lg2, le2)

@@ -1,9 +1,10 @@
 """Kernels of one replayed LoRA training step (config 3: batch 8, rank 8), aggregated by symbol: launches, average and total us per step.
+Only COMPLETE replays are counted (bench.trace_steps cuts the device-event stream at the step's last launch, the flat AdamW, and keeps
+the steps whose kernel sequences are identical): every per-step launch count is an integer by construction.
 usage: python tools/train_table.py [rank]"""
 import collections, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from torch.profiler import ProfilerActivity, profile
 from audioldm_with_lora_amd.scheduler import DDIMScheduler
 from audioldm_with_lora_amd.training import LoraTrainer
 
@@ -17,19 +18,15 @@ emb = torch.nn.functional.normalize(torch.randn(8, 512, generator=g), dim=-1).cu
 for _ in range(5):
     tr.step(lat, noise, t, emb)
 torch.cuda.synchronize()
-reps = 4
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
-    for _ in range(reps):
-        tr.step(lat, noise, t, emb)
-    torch.cuda.synchronize()
+per, span, kept = bench.trace_steps(lambda: tr.step(lat, noise, t, emb), "adamw_flat", reps=6)
+assert per, "no complete step in the trace"
 agg = collections.defaultdict(lambda: [0, 0.0])
-first, last = None, None
-for e in prof.events():
-    if e.device_type == torch.autograd.DeviceType.CUDA:
-        agg[e.name][0] += 1
-        agg[e.name][1] += e.time_range.elapsed_us()
-tot = sum(v[1] for v in agg.values()) / reps
-n = sum(v[0] for v in agg.values()) / reps
-print(f"{n:.0f} device activities per step, {tot:.0f} us of kernel time per step")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
-    print(f"{v[1] / reps:8.1f} us {v[0] / reps:6.1f}x {v[1] / v[0]:7.1f}  {k[:110]}")
+for name, us in per:
+    agg[name][0] += 1
+    agg[name][1] += us
+tot = sum(v[1] for v in agg.values())
+print(f"{len(per)} kernels per step, {tot:.0f} us of kernel time per step, span {span:.0f} us ({kept} complete steps averaged)")
+for fam, ms in bench.train_families(per).items():
+    print(f"  family {fam:18s} {ms:7.3f} ms")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{v[1]:8.1f} us {v[0]:4d}x {v[1] / v[0]:7.1f}  {k[:110]}")
