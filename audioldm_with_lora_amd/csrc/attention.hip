@@ -25,6 +25,22 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Round-4 experiments kept as compile-time switches (both OFF in the product build; numbers: B = 8, N = 1000, 8 heads x 32, replayed
+// graph, tools/bench_attn.py; profiles/r04_attention_ablation.txt):
+//   ATTN_ML    row sum l on the matrix pipe (register-constant ones fragment, 4 more MFMAs per tile) instead of VALU adds
+//   ATTN_FENCE hand-ordered tile: staging + prefetch behind the S^T MFMAs, exponentials interleaved with the P V MFMAs by sched_barrier
+//   ML 0 / FENCE 0 20.3 us | 0 / 1 21.1 | 1 / 0 21.0 | 1 / 1 21.9 -- neither helps, and the ablations say why: without the running
+//   maximum (21 VALU per tile) 20.6 us, without the 32 exponentials 18.2, without the global loads + staging 17.9, without all three
+//   13.5: what remains -- fragment reads, 8 MFMAs, 16 conversions and the barrier of each of the 16 tiles -- is a DEPENDENT CHAIN of
+//   ~1300 cycles per tile that two waves per SIMD (the grid is one 8-wave workgroup per CU at UNet batch 8) do not cover; at twice the
+//   batch (two workgroups per CU) the same kernel does twice the work in 36.7 us.  The instruction mix is not the limit at this size.
+#ifndef ATTN_ML
+#define ATTN_ML 0
+#endif
+#ifndef ATTN_FENCE
+#define ATTN_FENCE 0
+#endif
+
 namespace {
 
 constexpr int KV = 64;           // keys per tile
@@ -233,6 +249,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // summed l with 16 v_pk_add_f32 per tile on the grounds that MFMA and VALU time add up; tools/micro/mfma_valu_gap.hip (instruction
   // stream pinned by inline asm) shows they do not: an MFMA costs its wave 8 issue cycles, its 32 pipe cycles run under the next five
   // VALU instructions (and under the SIMD's other wave), and this loop is VALU-issue-bound -- 4 x 8 issue cycles replace 16 packed adds.
+  constexpr bool ML = Cfg::VL && ATTN_ML;
+  float l_run = 0.f;                            // VL without ML: this lane's share of l (its 32 keys of every tile), VALU adds
   f32x16 lacc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
@@ -274,6 +292,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         }
     }
     // lane-local: this lane's query column; deferred rescale
+#ifdef ATTN_DIAG_NOMAX
+    float mx = s[0][0];
+#else
     float mx0 = max3f(s[0][0], s[0][1], s[0][2]), mx1 = max3f(s[1][0], s[1][1], s[1][2]);   // two independent chains
 #pragma unroll
     for (int i = 3; i < 15; i += 2) {
@@ -285,6 +306,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
       mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
     }
+#endif
     // excess of this tile's maximum over the running one, in the scaled (log2) domain
     const float ex = PRESCALED ? mx : fmaf(mx, c, -m_run);
     if (first || !__all(ex <= RESCALE_THR)) {
@@ -296,9 +318,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         for (int t = 0; t < DT; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) o[t][i] *= alpha;                // includes l (row DP)
-        if constexpr (Cfg::VL) {
+        if constexpr (ML) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
+        } else if constexpr (Cfg::VL) {
+          l_run *= alpha;
         }
       }
       if (PRESCALED) {
@@ -310,31 +334,48 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
         for (int i = 0; i < 16; ++i) minit[i] = -m_run;
       }
     }
+    // ---- p = exp2(s'), O^T += V^T P^T (row DP of V^T is ones: l accumulates alongside; ML: one more MFMA against a register of ones).
+    // One 16-key step at a time, fenced: the 8 exponentials + 4 conversions of step s2 + 1 issue while the matrix pipe works on step
+    // s2's MFMAs (an MFMA costs its wave 8 issue cycles; its 32 pipe cycles hide under up to ~24 cycles of the wave's next VALU
+    // instructions -- tools/micro/mfma_valu_gap.hip).  The barrier at the end of every tile keeps the SIMD's two waves in phase, so
+    // nothing but the wave's own instruction stream fills those cycles: left to the scheduler, all 32 exponentials came first and
+    // the MFMAs ran back to back behind them, pipe-bound in both waves at once.
     bf16x8 pf[4];
+    auto vfrag = [&](int t, int s2) {
+      const char* vrow = Vs + buf * Cfg::VBYTES + (t * 32 + r) * VS + (16 * s2 + 4 * hh) * 2;
+      const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+      const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+      return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    };
+    bf16x8 vf[2][DT];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int t = 0; t < DT; ++t) vf[0][t] = vfrag(t, 0);
 #pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const float e0 = PRESCALED ? s[sub][i] : fmaf(s[sub][i], c, -m_run);
-        const float e1 = PRESCALED ? s[sub][i + 1] : fmaf(s[sub][i + 1], c, -m_run);
-        pf[sub * 2 + (i >> 3)][i & 7] = (bf16)__builtin_amdgcn_exp2f(e0);
-        pf[sub * 2 + (i >> 3)][(i & 7) + 1] = (bf16)__builtin_amdgcn_exp2f(e1);
+    for (int s2 = 0; s2 < 4; ++s2) {          // 4 K-steps of 16 keys
+      const int sub = s2 >> 1, i0 = (s2 & 1) * 8;
+      if (s2 + 1 < 4) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) vf[(s2 + 1) & 1][t] = vfrag(t, s2 + 1);   // next step's V^T fragments: requested before this step's exponentials
       }
-    if constexpr (Cfg::VL) {
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[s2], lacc, 0, 0, 0);
+      for (int i = 0; i < 8; i += 2) {
+        const float e0 = PRESCALED ? s[sub][i0 + i] : fmaf(s[sub][i0 + i], c, -m_run);
+        const float e1 = PRESCALED ? s[sub][i0 + i + 1] : fmaf(s[sub][i0 + i + 1], c, -m_run);
+#ifdef ATTN_DIAG_NOEXP
+        const float p0 = e0, p1 = e1;
+#else
+        const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+#endif
+        if constexpr (Cfg::VL && !ML) l_run += p0 + p1;
+        pf[s2][i] = (bf16)p0;
+        pf[s2][i + 1] = (bf16)p1;
+      }
+      if (ATTN_FENCE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2 & 1][t], pf[s2], o[t], 0, 0, 0);
+      if constexpr (ML) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[s2], lacc, 0, 0, 0);
+      if (ATTN_FENCE) __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- O^T += V^T P^T (row DP of V^T is ones: l accumulates alongside) ----
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {  // 4 K-steps of 16 keys
-        const char* vrow = Vs + buf * Cfg::VBYTES + (t * 32 + r) * VS + (16 * s2 + 4 * hh) * 2;
-        const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[t], 0, 0, 0);
-      }
   };
   // (wave-uniform) a key group past the last tile of an odd count sits that iteration out
   auto mine = [&](int it) { return SP == 1 || (it * SP + grp) * KV < Nk; };
@@ -352,14 +393,32 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // iteration it+1 -- two iterations of flight time (one iteration, ~0.5 us, does not cover an L2 miss)
   auto iteration = [&](int it, auto curc) {     // curc: the register set that is free (its tile-group was staged last iteration)
     constexpr int CUR = decltype(curc)::value;
+    // Order inside a tile: the S^T MFMAs first, then -- in their shadow, nothing depends on them yet -- the next tile's staging
+    // (registers -> LDS; its buffer was last read before the barrier that ended the previous iteration) and the prefetch of the tile
+    // after it (scalar descriptor arithmetic + buffer loads), then the softmax and the P V MFMAs.  Fenced, because left alone the
+    // scheduler put the staging behind the last P V MFMA, where nothing runs beside it.
+    f32x16 s[2];
+    const bool me = mine(it);
+#if ATTN_FENCE
+    if (me) scores(it, s);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < niter) stage((it & 1) ^ 1, std::integral_constant<int, CUR ^ 1>{}, (it + 1) * SP * KV);
     prefetch((it + 2) * SP * KV, curc);         // (unconditional: past the last tile the descriptor's bound is 0 -> zeros, no traffic;
                                                 //  a fixed number of loads per iteration lets the compiler count them in s_waitcnt)
-    if (mine(it)) {
-      f32x16 s[2];
+    __builtin_amdgcn_sched_barrier(0);
+    if (me) softmax_pv(it, s);
+#else
+#ifndef ATTN_DIAG_NOLOAD
+    prefetch((it + 2) * SP * KV, curc);
+#endif
+    if (me) {
       scores(it, s);
       softmax_pv(it, s);
     }
+#ifndef ATTN_DIAG_NOLOAD
     if (it + 1 < niter) stage((it & 1) ^ 1, std::integral_constant<int, CUR ^ 1>{}, (it + 1) * SP * KV);
+#endif
+#endif
     __syncthreads();
   };
   for (int it = 0; it < niter; it += 2) {
@@ -380,7 +439,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mine[(1 + t * 16 + i) * 64 + lane] = o[t][i];
-      mine[(1 + DT * 16) * 64 + lane] = lacc[0];
+      mine[(1 + DT * 16) * 64 + lane] = ML ? lacc[0] : l_run;
     }
     __syncthreads();
     if (grp > 0) return;
@@ -396,14 +455,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * a0 + peer[(1 + t * 16 + i) * 64 + lane] * a1;   // l (row DP) merges like any row
       lacc[0] = lacc[0] * a0 + peer[(1 + DT * 16) * 64 + lane] * a1;
+      l_run = l_run * a0 + peer[(1 + DT * 16) * 64 + lane] * a1;
     }
   }
 
   // ---- normalise and store: lane owns query q0 + r, rows of O^T are head-dim indices ----
   // l sits in O^T row DP: register ONES_I of tile ONES_T on the hh = 0 lanes (the hh = 1 lanes hold row DP + 4 there: zero padding)
   // (VL: every row of lacc holds the whole sum for this lane's query column -- all 64 keys of every tile went through the MFMA's k)
-  const float l_half = o[Cfg::ONES_T][Cfg::ONES_I];
-  const float l_tot = Cfg::VL ? lacc[0] : l_half + __shfl_xor(l_half, 32, 64);
+  const float l_half = (Cfg::VL && !ML) ? l_run : o[Cfg::ONES_T][Cfg::ONES_I];   // (VALU form: this lane's 32 keys per tile; the other 32 sit in lane ^ 32)
+  const float l_tot = ML ? lacc[0] : l_half + __shfl_xor(l_half, 32, 64);
   const float inv = 1.0f / l_tot;
   if (lse && hh == 0 && q0 + r < N)   // log2-domain log-sum-exp of the scaled scores: p = exp2(s*c - lse)
     lse[((long long)b * gridDim.y + head) * N + q0 + r] = m_run + __log2f(l_tot);

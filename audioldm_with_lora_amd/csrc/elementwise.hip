@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void ddim_step_fused_kernel(const float* __res
     *reinterpret_cast<f32x4*>(rowbias + tix * 4) = *reinterpret_cast<const f32x4*>(table + (long long)nxt * row_elems + tix * 4);
   __syncthreads();                                            // every thread of this workgroup has read the counter
   if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acq_rel at agent scope: the release half orders this workgroup's reads of step_idx[0] before its ticket, the acquire half orders
+    // the last workgroup's stores below after every other workgroup's ticket -- by the memory model, not by an incidental s_waitcnt
+    const unsigned done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {                              // last workgroup: nobody will read step_idx[0] again in this launch
       ticket[0] = 0;
       step_idx[0] = nxt;

@@ -104,10 +104,15 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   d.tiles_n = 0; d.tiles_m = 0; d.nwg = 0;
   ALDM_CHECK_ARG(p->xcd_map >= 0 && p->xcd_map <= 2, "igemm: xcd_map must be 0 (auto), 1 (activation-stationary) or 2 (weight-stationary)");
   {
-    // which operand an XCD's L2 keeps (igemm_work_item): the one that would otherwise be streamed by all eight L2s is the larger one
+    // which operand an XCD's L2 keeps (igemm_work_item).  Measured (round 4, profiles/r04_fetch_xcd_*.json + r04_step_table_xcd_*.txt):
+    // weight-stationary more than halves the fabric fetches of the 252- / 64-token levels' launches (21.6 -> 9.8 MiB per launch on the
+    // dominant symbol) and the split-K launches among them get ~1 us SLOWER (eight co-scheduled M-tiles of an XCD then ask one L2
+    // channel for the same weight lines at the same instant; the re-fetches of the M-major map were Infinity-Cache hits, not HBM
+    // traffic); unsplit launches with weights > activations gain (GEGLU at M = 512: 15.8 -> 14.5 us).  So: auto = weight-stationary
+    // only for an unsplit launch whose weight matrix is the larger operand.
     const unsigned long long act = 2ull * p->B * p->IH * p->IW * Ctot + 2ull * p->B * p->OH * p->OW * Cext;
     const unsigned long long wgt = 2ull * p->Cout * p->Kpad;
-    d.xmap = p->xcd_map ? p->xcd_map - 1 : (wgt > act ? 1 : 0);
+    d.xmap = p->xcd_map ? p->xcd_map - 1 : ((wgt > act && p->splits <= 1) ? 1 : 0);
   }
   {
     const unsigned long long xb = 2ull * p->B * p->IH * p->IW * p->Cin, x2b = 2ull * p->B * p->IH * p->IW * p->Cin2;

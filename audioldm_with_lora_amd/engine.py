@@ -108,7 +108,10 @@ class DenoiseEngine:
 
     def _prime(self):
         """The single-chain step gathers the NEXT step's time-embedding row at its end (ops.ddim_step_fused); the row of the
-        step the counter stands at is put in place here, whenever the counter or the table changes outside the graph."""
+        step the counter stands at is put in place here, whenever the counter or the table changes outside the graph.  The fused
+        step's last-workgroup ticket is put back to rest as well: a launch that was aborted midway would otherwise leave it non-zero
+        for every later replay."""
+        self.ticket.zero_()
         if self.temb is not None and self.chains == 1:
             ops.gather_row(self.temb[0], self.step_idx, self.rowbias[0])
 

@@ -127,7 +127,8 @@ typedef struct {
      the kernel hands each XCD a contiguous range of (M-tile, N-tile, K-split) work items.  1 = activation-stationary (an XCD owns a band
      of output rows: right when activations >> weights), 2 = weight-stationary (an XCD owns a (K-slice, N-tile) range of the weights for
      every row: right at the UNet's 252- / 64-token levels, where every L2 would otherwise stream the whole weight matrix),
-     0 = auto: weight-stationary iff the weight matrix is larger than the activation image.  Speed only; results are identical. */
+     0 = auto: weight-stationary iff the launch is not split-K and the weight matrix is larger than the activation image (measured:
+     csrc/igemm.hip).  Speed only; results are identical. */
   int xcd_map;
 } aldm_igemm_t;
 

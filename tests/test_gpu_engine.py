@@ -37,6 +37,8 @@ def _setup(steps, g_scale, use_graph):
 def test_denoise_loop_matches_oracle(use_graph):
     got, want, eng = _setup(10, 2.5, use_graph)
     rel = float((got - want).norm() / want.norm())
+    import conftest
+    conftest.record(rel)
     assert torch.isfinite(got).all() and rel < 5e-2, rel
     assert int(eng.step_idx.item()) == 0          # wrapped after exactly n_steps
 

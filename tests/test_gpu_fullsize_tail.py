@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 def rel_l2(a, b):
-    return float((a - b).norm() / b.norm())
+    import conftest
+    return conftest.record(float((a - b).norm() / b.norm()))
 
 
 def _threads():

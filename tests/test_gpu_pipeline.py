@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def rel_l2(a, b):
-    return float((a - b).norm() / b.norm())
+    import conftest
+    return conftest.record(float((a - b).norm() / b.norm()))
 
 
 def test_vocoder_matches_transformers_golden():

@@ -67,7 +67,8 @@ def _grad_rel(mine, want):
         den += float((w ** 2).sum())
         if float(w.norm()) > 1e-3 * (den / n_pairs) ** 0.5:
             worst = min(worst, float((g * w).sum() / (g.norm() * w.norm() + 1e-30)) - 1.0)
-    return (num / den) ** 0.5, worst, n_pairs
+    import conftest
+    return conftest.record((num / den) ** 0.5, "grad_rel_l2"), worst, n_pairs
 
 
 @pytest.mark.parametrize("r,b", [(8, 2), (16, 1)])
@@ -121,6 +122,8 @@ def test_config3_batch8_graph_equals_eager_finite_independent_and_learning():
     g_graph = tr.flat.grads[:tr.flat.n].clone()
     assert abs(l_graph - l_eager) < 1e-3 * abs(l_eager)
     rel = float((g_graph - g_eager).norm() / g_eager.norm())
+    import conftest
+    conftest.record(rel, "graph_vs_eager_rel_l2")
     assert rel < 1e-3, rel
     # (c) per-sample independence of the loss
     singles = []

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def rel_l2(got, want):
-    return float((got - want).norm() / want.norm())
+    import conftest
+    return conftest.record(float((got - want).norm() / want.norm()))
 
 
 def _pair(cfg, seed=0):
