@@ -918,6 +918,43 @@ def attn_block64_ok(pw, N, H, d, ln_parts):
             and (pw.Rp == 0 or getattr(pw, "ranks_used", 99) <= 32))
 
 
+# The 252-token level's fused projection + attention launch (csrc/attn_block256.hip) is parity-green and OFF by default: measured in the
+# replayed step (round 4, gpurun_out/r4_step_b256.txt) 25.4 us per module against 12.9 + 8.1 us for the projection launch + the attention
+# launch.  A (sample, head) workgroup carries 31.5 MFLOP of projection + 12 MFLOP of attention on ONE CU (64 of 256 CUs busy): 4.4 us at
+# the MFMA peak of a CU before any latency, where the two launches spread the same work over the whole chip.  ALDM_ATTN_BLOCK256=1 turns it on.
+ATTN_BLOCK256 = os.environ.get("ALDM_ATTN_BLOCK256") == "1"
+
+
+def attn_block_ok(pw, N, H, d, ln_parts):
+    """Which (sample, head)-fused projection + attention launch takes this module: 64 (C = 640, N <= 64), 256 (C = 384, N <= 256) or 0."""
+    if attn_block64_ok(pw, N, H, d, ln_parts):
+        return 64
+    if (ATTN_BLOCK256 and N <= 256 and H == 8 and d == 48 and pw.N == 1152 and pw.Kpad == 384 and pw.ln_s is not None and ln_parts is not None
+            and ln_parts.shape[1] <= 16 and (pw.Rp == 0 or getattr(pw, "ranks_used", 99) <= 32)):
+        return 256
+    return 0
+
+
+def attn_block(x2d, pw, ln_parts, B, N, H, d):
+    """x2d [B*N, C] raw hidden state -> attention output [B*N, C] through the fused launch attn_block_ok() names."""
+    kind = attn_block_ok(pw, N, H, d, ln_parts)
+    if kind == 64:
+        return attn_block64(x2d, pw, ln_parts, B, N, H, d)
+    if kind != 256:
+        raise _lib.AldmError(f"attn_block: no fused projection + attention launch for N {N}, {H} heads x {d}")
+    _require_gpu(x2d)
+    Cc = H * d
+    assert x2d.dtype == torch.bfloat16 and x2d.is_contiguous() and tuple(x2d.shape) == (B * N, Cc)
+    assert ln_parts.dtype == torch.float32 and ln_parts.is_contiguous() and ln_parts.shape[0] == B * N
+    out = torch.empty(B * N, Cc, dtype=torch.bfloat16, device=x2d.device)
+    fl = B * (6.0 * N * Cc * Cc + 4.0 * N * N * Cc + (12.0 * N * Cc * getattr(pw, "ranks_used", 0) if pw.Rp else 0.0))
+    check(_launch(f"attn_block256_d{d}_n{N}", fl, 2.0 * (2 * B * N * Cc + 3 * Cc * Cc), lambda: _lib.load().aldm_attn_block256(
+        _p(x2d), _p(ln_parts), ln_parts.shape[1], _p(pw.w), pw.Kpad, _p(pw.bias), _p(pw.ln_s), _p(pw.lora_a), _p(pw.lora_b), pw.Rp,
+        getattr(pw, "ranks_used", 0) if pw.Rp else 0, _p(pw.ln_sa), _p(pw.ln_ca), pw.ln_eps, B, N, H, d, _p(out), _stream())),
+        "aldm_attn_block256")
+    return out
+
+
 def attn_block64(x2d, pw, ln_parts, B, N, H, d):
     """x2d [B*N, C] raw hidden state -> attention output [B*N, C]: LayerNorm-folded QKV projection with LoRA + 64-token attention,
     one launch (aldm_attn_block64)."""

@@ -221,7 +221,7 @@ def k1_sites(rows, ubatch, rank_lora):
         if not site:
             continue
         s = sites.setdefault(site, dict(modules=0, us=0.0, ev_us=0.0, parts={}))
-        part = ("qkv_lora+attention" if label.startswith("attn_block64") else "attention" if label.startswith("attention")
+        part = ("qkv_lora+attention" if label.startswith("attn_block") else "attention" if label.startswith("attention")
                 else ("qkv_lora" if "_vt" in label else "out_proj_lora"))
         s["parts"][part] = s["parts"].get(part, 0.0) + us
         s["us"] += us
@@ -339,7 +339,7 @@ def bench_pipeline(unet, batch, seconds, nsteps, guidance, seed_off=0):
     return min(times), first, legs
 
 
-TRAIN_FAMILIES = (("attention_bwd", ("attn_bwd",)), ("attention_fwd", ("attention_kernel", "attn_block64")),
+TRAIN_FAMILIES = (("attention_bwd", ("attn_bwd",)), ("attention_fwd", ("attention_kernel", "attn_block")),
                   ("gemm_lora_site", ("igemm_pipe_kernel<64, 64, 2, 2, 32", "igemm_pipe_kernel<128, 64, 2, 2, 32", "igemm_pipe_kernel<64, 128, 2, 2, 32",
                                       "igemm_pipe_kernel<128, 128, 2, 2, 32", "igemm_pipe_kernel<64, 64, 2, 2, 64", "igemm_pipe_kernel<128, 64, 2, 2, 64",
                                       "igemm_pipe_kernel<64, 128, 2, 2, 64", "igemm_pipe_kernel<128, 128, 2, 2, 64", "pgemm_kernel")),

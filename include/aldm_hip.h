@@ -268,6 +268,15 @@ int aldm_attn_block64(const void* x, const float* ln_parts, int ln_nparts, const
                       const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used, const float* ln_sa,
                       const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out, void* stream);
 
+/* The same launch for the UNet's 252-token level (C = 384 = 8 heads x 48, N <= 256 tokens per sample: 63 x 4 for a 10 s clip, 64 x 4 in
+   training): a (sample, head) workgroup of 8 waves keeps its tokens of X in registers, streams the head's 144 weight rows once and runs
+   the 256 x 256 attention from LDS -- the projection launch, the attention launch and the HBM round trip of Q | K | V^T between them
+   become one launch (csrc/attn_block256.hip).  Operands exactly as aldm_attn_block64.  diffusers Attention under
+   [REF script/train/train_audioldm_lora.py:539-546] / [REF script/inference/generate_audio.py:47-52]. */
+int aldm_attn_block256(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+                       const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used, const float* ln_sa,
+                       const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out, void* stream);
+
 /* Same, additionally writing the log2-domain log-sum-exp of the scaled scores, lse [B][H][N] fp32 (training). */
 /* Same core with a per-batch-item key count kv_len[B] (int32, device): keys >= kv_len[b] are excluded exactly as an
    additive -inf attention_mask excludes right-padded tokens, and the key loop stops at the last valid tile.  Query

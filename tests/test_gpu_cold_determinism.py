@@ -151,6 +151,25 @@ def test_attn_block64(ops):
     alternate(lambda k: (ops.attn_block64(probs[k][0], probs[k][1], probs[k][2], B, N, H, d),))
 
 
+def test_attn_block256(ops, monkeypatch):
+    monkeypatch.setattr(ops, "ATTN_BLOCK256", True)
+    g = torch.Generator().manual_seed(256)
+    B, N, H, d, r = 8, 252, 8, 48, 4
+    Cc = H * d
+    probs = []
+    for k in range(2):
+        x = dv(torch.randn(B * N, Cc, generator=g) * 1.3 + 0.2)
+        pw = ops.pack_linear_ln((torch.randn(3 * Cc, Cc, generator=g) / math.sqrt(Cc)).to(DEV), None,
+                                (torch.randn(Cc, generator=g) * 0.3 + 1).to(DEV), (torch.randn(Cc, generator=g) * 0.2).to(DEV))
+        ops.attach_lora(pw, [(i * Cc, Cc, (torch.randn(r, Cc, generator=g) / math.sqrt(Cc)).to(DEV),
+                              (torch.randn(Cc, r, generator=g) * 0.3).to(DEV), 2.0) for i in range(3)])
+        xs = x.float().view(B * N, Cc // 64, 64)
+        parts = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).contiguous()
+        probs.append((x, pw, parts))
+    assert ops.attn_block_ok(probs[0][1], N, H, d, probs[0][2]) == 256
+    alternate(lambda k: (ops.attn_block(probs[k][0], probs[k][1], probs[k][2], B, N, H, d),))
+
+
 def test_attention_wide(ops):
     """attention_wide_kernel: K / V^T tiles by LDS-DMA, keys zero-padded to a multiple of 32 through the descriptor"""
     g = torch.Generator().manual_seed(512)

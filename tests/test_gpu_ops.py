@@ -522,6 +522,42 @@ def test_attn_block64_projection_and_attention_in_one_launch(ops, B, N, r):
     close(ref, want, rtol=3e-2, atol=2.5e-2 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,N,r", [(8, 252, 4), (2, 256, 0), (3, 100, 8), (1, 17, 10), (8, 256, 4)])
+def test_attn_block256_projection_and_attention_in_one_launch(ops, monkeypatch, B, N, r):
+    """aldm_attn_block256 (the 252-token level: C = 384 = 8 heads x 48): LayerNorm (folded, statistics handed over) -> to_q | to_k | to_v
+    with LoRA -> softmax(Q K^T) V per (sample, head), against the two-launch path it replaces and against torch fp32 on the
+    bf16-rounded operands.  N = 252 / 256: the inference / training token counts; 100, 17: ragged (whole query tiles and waves of
+    padding, keys masked); r = LoRA rank per projection (3 r <= 16: one rank tile, <= 32: two)."""
+    H, d = 8, 48
+    Cc = H * d
+    g = torch.Generator().manual_seed(32)
+    x = bf(torch.randn(B * N, Cc, generator=g) * 1.3 + 0.2)
+    wq, wk, wv = (bf(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc)) for _ in range(3))
+    gm, bt = torch.randn(Cc, generator=g) * 0.3 + 1, torch.randn(Cc, generator=g) * 0.2
+    xn = F.layer_norm(x, (Cc,), gm, bt, 1e-5)
+    lor = [(bf(torch.randn(r, Cc, generator=g) / math.sqrt(Cc)), bf(torch.randn(Cc, r, generator=g) * 0.3), 2.0) if r else None
+           for _ in range(3)]
+    q, k, v = (xn @ w.t() + (l[2] * (xn @ l[0].t()) @ l[1].t() if l else 0.0) for w, l in zip((wq, wk, wv), lor))
+    sp = lambda t: t.view(B, N, H, d).transpose(1, 2)
+    want = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B * N, Cc)
+    qs = ops.LOG2E / math.sqrt(d)
+    pw = ops.pack_linear_ln(torch.cat([wq * qs, wk, wv]).to(DEV), None, gm.to(DEV), bt.to(DEV))
+    ops.attach_lora(pw, [None if l is None else (i * Cc, Cc, l[0].to(DEV), l[1].to(DEV), l[2] * (qs if i == 0 else 1.0))
+                         for i, l in enumerate(lor)])
+    xd = x.to(torch.bfloat16).to(DEV)
+    xs = xd.float().view(B * N, Cc // 64, 64)
+    parts = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).contiguous()
+    monkeypatch.setattr(ops, "ATTN_BLOCK256", True)                      # (off by default: slower than the two launches it fuses, ops.py)
+    assert ops.attn_block_ok(pw, N, H, d, parts) == 256
+    out = ops.attn_block(xd, pw, parts, B, N, H, d)
+    npad = (N + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, npad, dtype=torch.bfloat16, device=DEV)
+    qk = ops.conv(xd.view(B, 1, N, Cc), pw, vt=vt, vt_col0=2 * Cc, vt_ld=npad, vt_batch_stride=Cc * npad, ln_parts=parts)
+    ref = ops.attention(qk.view(B * N, 2 * Cc), vt, B, N, H, d, prescaled=True)
+    close(out, ref.float().cpu(), rtol=2e-2)
+    close(out, want, rtol=3e-2, atol=2.5e-2 * float(want.abs().max()))
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])
