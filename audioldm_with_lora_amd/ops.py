@@ -971,6 +971,31 @@ def attn_block64(x2d, pw, ln_parts, B, N, H, d):
     return out
 
 
+HIFIGAN_PAIR = os.environ.get("ALDM_NO_HIFIGAN_PAIR") != "1"        # A/B aid: the vocoder's low-channel stages back on aldm_igemm
+
+
+def hifigan_respair_ok(x, c1, c2, dil):
+    """Can one aldm_hifigan_respair launch take this (convs1[q], convs2[q]) pair?  (C = 32 / 64 channels, 3 / 7 / 11 taps, dilation <= 5.)"""
+    Cc = x.shape[3]
+    return (HIFIGAN_PAIR and x.shape[1] == 1 and c1.N == Cc and c2.N == Cc and c1.Cin == Cc and c2.Cin == Cc and c1.KH == 1 and c2.KH == 1
+            and c1.KW == c2.KW and c1.bias is not None and c2.bias is not None
+            and bool(_lib.load().aldm_hifigan_respair_supported(Cc, c1.KW, dil)))
+
+
+def hifigan_respair(x, c1, c2, dil, slope, alpha=1.0, res2=None, post_act=ACT_NONE, post_slope=0.0):
+    """x [B, 1, T, C] bf16 residual stream -> post_act(alpha (x + conv2(lrelu(conv1(lrelu(x))))) + res2), one launch."""
+    _require_gpu(x)
+    B, _, T, Cc = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and (res2 is None or (res2.shape == x.shape and res2.is_contiguous()))
+    out = torch.empty_like(x)
+    K = c1.KW
+    fl = 2.0 * 2.0 * B * T * Cc * Cc * K
+    check(_launch(f"hifigan_pair_c{Cc}_k{K}_d{dil}|M{B * T}", fl, 2.0 * B * T * Cc * (2 + (1 if res2 is not None else 0)), lambda: _lib.load().aldm_hifigan_respair(
+        _p(x), B, T, Cc, _p(c1.w), c1.Kpad, _p(c1.bias), dil, _p(c2.w), c2.Kpad, _p(c2.bias), K, slope, alpha, _p(res2), post_act, post_slope,
+        _p(out), _stream())), "aldm_hifigan_respair")
+    return out
+
+
 WIDE_HEAD_DIMS = (128, 256, 512)
 
 

@@ -6,7 +6,10 @@ Drop-in for `transformers.SpeechT5HifiGan` as the reference uses it: `from_pretr
   [REF script/inference/generate_audio.py:47-52].  Spec: SURVEY.md B.6
 (transformers/models/speecht5/modeling_speecht5.py:2887-3069); state-dict keys identical to the HF class.
 
-Everything is the implicit-GEMM MFMA kernel over channels-last [B, T, C] sequences:
+The 32- / 64-channel stages (320 k - 640 k samples, 18 of the 45 residual (conv1, conv2) pairs) run each pair as ONE launch of the
+vocoder's own kernel (csrc/hifigan.hip, aldm_hifigan_respair: the run is activated on its way into LDS, conv1's output never leaves
+LDS, both convolutions' weights stay in registers as MFMA fragments, residual / MRF mean / next activation in the epilogue).
+Everything else is the implicit-GEMM MFMA kernel over channels-last [B, T, C] sequences:
   * Conv1d(k, dilation d)            -> 1 x k filter, dil_w = d
   * ConvTranspose1d(k, stride u, p)  -> u phase convolutions: output t = u q + phi - p takes taps j = phi + u i from
     input q - i; each phase is a plain conv with n = ceil((k - phi)/u) taps, run with dil_w = -1 and written with an
@@ -159,8 +162,27 @@ class SpeechT5HifiGan(nn.Module):
         nstage = len(P.ups)
         for i, up in enumerate(P.ups):
             T = (T - 1) * up.stride - 2 * up.padding + up.k
-            h, ha = run_conv_transpose1d(up, a, T, post_act=ACT_LRELU, post_slope=slope, out2=True)
             last = i == nstage - 1
+            # the 32- / 64-channel stages: every (convs1[q], convs2[q]) pair is ONE launch (aldm_hifigan_respair: the run is activated on
+            # its way into LDS, conv1's output never leaves LDS) -- no activated copy of the stream is needed from the up-sampler
+            fused = all(ops.hifigan_respair_ok(torch.empty(0, 1, 0, up.phases[0].N), rb.c1[q], rb.c2[q], rb.dil[q])
+                        for rb in P.res[i * nk:(i + 1) * nk] for q in range(len(rb.c1)))
+            if fused:
+                h = run_conv_transpose1d(up, a, T)
+                acc = None
+                for j in range(nk):
+                    rb = P.res[i * nk + j]
+                    r, npairs = h, len(rb.c1)
+                    for q, (c1, c2, d) in enumerate(zip(rb.c1, rb.c2, rb.dil)):
+                        if q < npairs - 1:
+                            r = ops.hifigan_respair(r, c1, c2, d, slope)
+                        else:
+                            fin = j == nk - 1
+                            acc = ops.hifigan_respair(r, c1, c2, d, slope, alpha=1.0 / nk, res2=acc,
+                                                      post_act=(ACT_LRELU if fin else ACT_NONE), post_slope=(0.01 if last else slope))
+                a = acc
+                continue
+            h, ha = run_conv_transpose1d(up, a, T, post_act=ACT_LRELU, post_slope=slope, out2=True)
             acc = None
             for j in range(nk):
                 rb = P.res[i * nk + j]

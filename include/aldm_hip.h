@@ -304,6 +304,22 @@ int aldm_attention_bwd(const void* q, const void* k, const void* v, int ld, cons
                        float* delta, int B, int N, int H, int d, float scale, void* dq, void* dk, void* dv,
                        int ldg, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * HiFi-GAN residual-block pair as ONE launch (csrc/hifigan.hip), for the vocoder's 32- / 64-channel stages:
+ *     out = post_act( alpha * ( x + conv2(lrelu(conv1(lrelu(x)))) ) + res2 )
+ * conv1: K taps, dilation dil, "same" zero padding; conv2: K taps, dilation 1; both C -> C with bias.  x / res2 / out bf16 [B][T][C]
+ * (channels-last); w1 / w2 bf16 [C][ld] with K index = tap * C + cin (ops.pack_conv of the Conv1d weight viewed as a 1 x K filter).
+ * One (convs1[q], convs2[q]) step of transformers' HifiGanResidualBlock.forward (modeling_speecht5.py:2887-2950); alpha = 1 / 3 and
+ * res2 = the running sum fold SpeechT5HifiGan.forward's mean over the three residual blocks into the last pair of each block, post_act
+ * = the leaky-relu in front of the next up-sampler (slope 0.1) or of conv_post (slope 0.01).  The vocoder the reference loads at
+ * [REF script/train/train_audioldm_lora.py:371] and runs inside AudioLDMPipeline.__call__ [REF script/inference/generate_audio.py:47-52].
+ * Supported: C in {32, 64}, K in {3, 7, 11}, dil 1..5 (aldm_hifigan_respair_supported); other stages run on aldm_igemm.
+ * ------------------------------------------------------------------------------------------ */
+int aldm_hifigan_respair_supported(int C, int K, int dil);
+int aldm_hifigan_respair(const void* x, int B, int T, int C, const void* w1, int ld1, const float* b1, int dil, const void* w2, int ld2,
+                         const float* b2, int K, float slope, float alpha, const void* res2, int post_act, float post_slope, void* out,
+                         void* stream);
+
 /* Row softmax of fp32 scores [rows][cols] (ld) -> bf16 probabilities (VAE mid-block attention, N=4000, d=512). */
 int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out, void* stream);
 

@@ -558,6 +558,36 @@ def test_attn_block256_projection_and_attention_in_one_launch(ops, monkeypatch, 
     close(out, want, rtol=3e-2, atol=2.5e-2 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,T,C,K,d,mrf", [(2, 1000, 32, 3, 1, False), (1, 777, 32, 11, 5, True), (2, 600, 64, 7, 3, True), (1, 300, 64, 11, 5, False),
+                                            (1, 50, 32, 7, 1, True), (3, 256, 64, 3, 3, False)])
+def test_hifigan_residual_pair_one_launch(ops, B, T, C, K, d, mrf):
+    """aldm_hifigan_respair: x + conv2(lrelu(conv1(lrelu(x)))) (one step of HifiGanResidualBlock.forward), optionally folded into the MRF
+    mean and the next stage's leaky-relu, against torch fp32 on the bf16-rounded operands and against the two aldm_igemm launches it
+    replaces.  Ragged lengths (T % 256 != 0, T < one tile), both channel counts, every tap count, dilations 1 / 3 / 5."""
+    g = torch.Generator().manual_seed(77 + K)
+    x = bf(torch.randn(B, C, T, generator=g))
+    w1, w2 = bf(torch.randn(C, C, K, generator=g) / math.sqrt(C * K)), bf(torch.randn(C, C, K, generator=g) / math.sqrt(C * K))
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    acc = bf(torch.randn(B, C, T, generator=g)) if mrf else None
+    t = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w1, b1, dilation=d, padding=(K * d - d) // 2), 0.1)
+    want = x + F.conv1d(bf(t), w2, b2, padding=(K - 1) // 2)
+    if mrf:
+        want = F.leaky_relu(want / 3 + acc, 0.01)
+    cl = lambda v: v.transpose(1, 2).unsqueeze(1).contiguous().to(torch.bfloat16).to(DEV)       # [B, 1, T, C] channels-last
+    c1 = ops.pack_conv(w1.unsqueeze(2).to(DEV), b1.to(DEV))
+    c2 = ops.pack_conv(w2.unsqueeze(2).to(DEV), b2.to(DEV))
+    xd = cl(x)
+    assert ops.hifigan_respair_ok(xd, c1, c2, d)
+    kw = dict(alpha=1.0 / 3, res2=cl(acc), post_act=ops.ACT_LRELU, post_slope=0.01) if mrf else {}
+    got = ops.hifigan_respair(xd, c1, c2, d, 0.1, **kw)
+    close(got[:, 0].transpose(1, 2), want, rtol=2e-2)
+    # the two launches it replaces (same packed weights, same bf16 rounding of the intermediate)
+    ra = ops.conv(xd, ops.pack_conv(torch.eye(C).view(C, C, 1, 1).to(DEV), None), out_act=ops.ACT_LRELU, out_slope=0.1)      # lrelu(x)
+    tt = ops.conv(ra, c1, pad=(0, (K * d - d) // 2), dil=(1, d), out_act=ops.ACT_LRELU, out_slope=0.1)
+    two = ops.conv(tt, c2, pad=(0, (K - 1) // 2), res=xd, **(dict(alpha=1.0 / 3, res2=cl(acc), post_act=ops.ACT_LRELU, post_slope=0.01) if mrf else {}))
+    close(got, two.float().cpu(), rtol=1.5e-2)
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])

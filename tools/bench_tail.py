@@ -39,5 +39,5 @@ agg = {}
 for label, fl, by, s, e, _site in ops.PROFILE:
     a = agg.setdefault(label, [0.0, 0, 0.0])
     a[0] += s.elapsed_time(e); a[1] += 1; a[2] += fl
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
     print(f"{k:70s} {v[1]:3d}x {v[0]:8.2f} ms {v[2] / v[0] / 1e9 if v[0] else 0:7.1f} TF/s")
