@@ -114,6 +114,7 @@ PROTOTYPES = {
     "aldm_hifigan_respair_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "aldm_hifigan_respair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "aldm_conv1d_to1": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aldm_attention_wide": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_attention_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,

@@ -156,6 +156,56 @@ int launch_pair(const PairArgs& a, hipStream_t st) {
   return aldm_launch_status("hifigan_respair");
 }
 
+// ---- conv_post: Conv1d(C -> 1, K taps, "same" padding) + tanh, fp32 out -- SpeechT5HifiGan.forward's last two lines (modeling_speecht5.py:3059-3061).
+// One output channel: as a GEMM it fills 1 of 64 tile columns (0.10 ms on the generic kernel: 24 TFLOP/s, 400 GB/s).  Here it is the
+// HBM-bound stencil it is: a workgroup stages 256 + K - 1 positions of the (already activated) input in LDS, each thread owns one output
+// and runs its K * C multiply-adds on the VALU with the weights broadcast from LDS; the input is read once, the output written once.
+struct PostArgs {
+  const bf16* x; const bf16* w; const float* bias; float* out;
+  int B, T, C, K, tiles_per_item, act;
+};
+
+__global__ __launch_bounds__(256) void conv1d_to1_kernel(const PostArgs p) {
+  constexpr int TT = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int C = p.C, K = p.K, P = (K - 1) / 2;
+  const int XSTR = C * 2 + 16;                                // padded rows: consecutive lanes' 16-byte reads spread over the banks
+  char* const xs = smem;                                      // [TT + K - 1][XSTR]
+  bf16* const ws = reinterpret_cast<bf16*>(smem + (TT + K - 1) * XSTR);   // [K][C]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / p.tiles_per_item, t0 = (blockIdx.x - b * p.tiles_per_item) * TT;
+  const int cpr = C / 8;
+  const bf16* xb = p.x + (long long)b * p.T * C;
+  for (int c = tid; c < (TT + K - 1) * cpr; c += 256) {
+    const int row = c / cpr, ch = c - row * cpr, t = t0 - P + row;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t >= 0 && t < p.T) v = *reinterpret_cast<const bf16x8*>(xb + (long long)t * C + ch * 8);
+    *reinterpret_cast<bf16x8*>(xs + row * XSTR + ch * 16) = v;
+  }
+  for (int c = tid; c < K * cpr; c += 256) *reinterpret_cast<bf16x8*>(ws + c * 8) = *reinterpret_cast<const bf16x8*>(p.w + c * 8);
+  __syncthreads();
+  const int t = t0 + tid;
+  float a0 = 0.f, a1 = 0.f;
+  for (int tap = 0; tap < K; ++tap) {
+    const char* xr = xs + (tid + tap) * XSTR;
+    const bf16* wr = ws + tap * C;
+    for (int ch = 0; ch < cpr; ++ch) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + ch * 16);
+      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + ch * 8);     // same address in every lane: an LDS broadcast
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        a0 = fmaf((float)xv[i], (float)wv[i], a0);
+        a1 = fmaf((float)xv[i + 1], (float)wv[i + 1], a1);
+      }
+    }
+  }
+  if (t < p.T) {
+    float v = a0 + a1 + (p.bias ? p.bias[0] : 0.f);
+    if (p.act == ALDM_ACT_TANH) v = tanhf(v);
+    p.out[(long long)b * p.T + t] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int aldm_hifigan_respair_supported(int C, int K, int dil) {
@@ -180,4 +230,18 @@ extern "C" int aldm_hifigan_respair(const void* x, int B, int T, int C, const vo
   ALDM_PAIR(64, 3); ALDM_PAIR(64, 7); ALDM_PAIR(64, 11);
 #undef ALDM_PAIR
   return ALDM_E_UNSUPPORTED;
+}
+
+extern "C" int aldm_conv1d_to1(const void* x, int B, int T, int C, const void* w, const float* bias, int K, int act, float* out,
+                               void* stream) {
+  ALDM_CHECK_ARG(x && w && out && B > 0 && T > 0, "conv1d_to1: null pointer / bad dims");
+  ALDM_CHECK_ARG(C % 8 == 0 && C >= 8 && C <= 128 && K >= 1 && K <= 15 && (K & 1), "conv1d_to1: C %% 8 == 0, C <= 128, odd K <= 15 (got C %d K %d)", C, K);
+  ALDM_CHECK_ARG(act == ALDM_ACT_NONE || act == ALDM_ACT_TANH, "conv1d_to1: act NONE or TANH");
+  PostArgs a{(const bf16*)x, (const bf16*)w, bias, out, B, T, C, K, cdiv(T, 256), act};
+  const int lds = (256 + K - 1) * (C * 2 + 16) + K * C * 2;
+  static unsigned long long attr_done = 0;
+  if (lds > 48 * 1024)
+    if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(conv1d_to1_kernel), lds, &attr_done, "conv1d_to1")) return rc;
+  hipLaunchKernelGGL(conv1d_to1_kernel, dim3((unsigned)(B * a.tiles_per_item)), dim3(256), lds, (hipStream_t)stream, a);
+  return aldm_launch_status("conv1d_to1");
 }

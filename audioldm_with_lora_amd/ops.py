@@ -996,6 +996,18 @@ def hifigan_respair(x, c1, c2, dil, slope, alpha=1.0, res2=None, post_act=ACT_NO
     return out
 
 
+def conv1d_to1(x, pw, act=ACT_NONE):
+    """x [B, 1, T, C] bf16 (activated) -> fp32 [B, T]: Conv1d(C -> 1, K taps, same padding) (+ tanh) as one HBM-bound stencil launch.
+    pw = ops.pack_conv of the [1 (padded to 8), C, 1, K] weight: row 0 holds the filter in (tap, cin) order."""
+    _require_gpu(x)
+    B, _, T, Cc = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and pw.Cin == Cc and pw.KH == 1
+    out = torch.empty(B, T, dtype=torch.float32, device=x.device)
+    check(_launch(f"conv1d_to1_c{Cc}_k{pw.KW}|M{B * T}", 2.0 * B * T * Cc * pw.KW, 2.0 * B * T * Cc + 4.0 * B * T, lambda: _lib.load().aldm_conv1d_to1(
+        _p(x), B, T, Cc, _p(pw.w), _p(pw.bias), pw.KW, act, _p(out), _stream())), "aldm_conv1d_to1")
+    return out
+
+
 WIDE_HEAD_DIMS = (128, 256, 512)
 
 

@@ -202,7 +202,9 @@ class SpeechT5HifiGan(nn.Module):
                         acc = ops.conv(t, c2, pad=(0, (rb.k - 1) // 2), res=r, alpha=1.0 / nk, res2=acc,
                                        post_act=(ACT_LRELU if fin else ACT_NONE), post_slope=(0.01 if last else slope))
             a = acc
-        w = ops.conv(a, P.post, pad=(0, 3), out_act=ACT_TANH, out_f32=True)
+        if a.shape[3] % 8 == 0 and a.shape[3] <= 128 and P.post.KW % 2 == 1 and P.post.KW <= 15:
+            return ops.conv1d_to1(a, P.post, act=ACT_TANH)       # one output channel: an HBM-bound stencil, not a GEMM with 1 live column
+        w = ops.conv(a, P.post, pad=(0, (P.post.KW - 1) // 2), out_act=ACT_TANH, out_f32=True)
         return w[:, 0, :, 0].contiguous()
 
     def forward(self, spectrogram):

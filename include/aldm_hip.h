@@ -320,6 +320,11 @@ int aldm_hifigan_respair(const void* x, int B, int T, int C, const void* w1, int
                          const float* b2, int K, float slope, float alpha, const void* res2, int post_act, float post_slope, void* out,
                          void* stream);
 
+/* Conv1d(C -> 1 channel, K taps, "same" zero padding) + optional tanh, fp32 out [B][T]: SpeechT5HifiGan.forward's conv_post + tanh
+   (modeling_speecht5.py:3059-3061) as the HBM-bound stencil it is (csrc/hifigan.hip).  x bf16 [B][T][C] channels-last (already
+   activated); w bf16 [K * C] with index tap * C + cin (row 0 of ops.pack_conv's matrix); bias fp32 [1] or NULL. */
+int aldm_conv1d_to1(const void* x, int B, int T, int C, const void* w, const float* bias, int K, int act, float* out, void* stream);
+
 /* Row softmax of fp32 scores [rows][cols] (ld) -> bf16 probabilities (VAE mid-block attention, N=4000, d=512). */
 int aldm_softmax_rows(const float* s, int rows, int cols, int ld_in, float scale, void* p, int ld_out, void* stream);
 

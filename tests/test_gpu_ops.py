@@ -588,6 +588,19 @@ def test_hifigan_residual_pair_one_launch(ops, B, T, C, K, d, mrf):
     close(got, two.float().cpu(), rtol=1.5e-2)
 
 
+@pytest.mark.parametrize("B,T,C,K", [(2, 1000, 32, 7), (1, 130, 64, 3), (3, 257, 8, 11), (1, 5, 32, 7)])
+def test_conv1d_to_one_channel_with_tanh(ops, B, T, C, K):
+    """aldm_conv1d_to1 (SpeechT5HifiGan's conv_post + tanh) against torch fp32 on the bf16-rounded operands."""
+    g = torch.Generator().manual_seed(90 + K)
+    x = bf(torch.randn(B, C, T, generator=g))
+    w = bf(torch.randn(1, C, K, generator=g) / math.sqrt(C * K))
+    b = torch.randn(1, generator=g) * 0.1
+    want = torch.tanh(F.conv1d(x, w, b, padding=(K - 1) // 2))[:, 0]
+    pw = ops.pack_conv(torch.cat([w, torch.zeros(7, C, K)]).unsqueeze(2).to(DEV), torch.cat([b, torch.zeros(7)]).to(DEV))
+    got = ops.conv1d_to1(x.transpose(1, 2).unsqueeze(1).contiguous().to(torch.bfloat16).to(DEV), pw, act=ops.ACT_TANH)
+    close(got, want, rtol=1e-3, atol=2e-3)
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])
