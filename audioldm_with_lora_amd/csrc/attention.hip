@@ -45,6 +45,22 @@ namespace {
 
 constexpr int KV = 64;           // keys per tile
 constexpr int VS = 136;          // V^T LDS row stride in bytes (64 keys * 2 B + 8 B pad): conflict-free ds_read_b64
+constexpr int VS8 = 72;          // the same for one-byte (e4m3) elements: 64 keys + 8 B pad
+
+// bf16 x 8 -> OCP e4m3 x 8 (the fp8 operand form of BASELINE config 5; saturating conversion v_cvt_pk_fp8_f32)
+__device__ __forceinline__ uint2 bf16x8_to_fp8(const bf16x8 v) {
+  const uint4 u = __builtin_bit_cast(uint4, v);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+  int o[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+    if (i & 1) o[i >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, o[i >> 1], true);
+    else o[i >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, o[i >> 1], false);
+  }
+  return make_uint2((unsigned)o[0], (unsigned)o[1]);
+}
+__device__ __forceinline__ long pack2(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
 
 constexpr float RESCALE_THR = 5.0f;   // log2 units: the running max is raised only when a tile's max exceeds it by more than this
 
@@ -54,7 +70,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   return d;
 }
 
-template <int DP>
+template <int DP, bool FP8 = false>
 struct AttnCfg {
   static constexpr int DK = DP / 16;                       // QK^T k-steps
   // VL: the row sum l = sum_k p is accumulated by VALU adds instead of the row of ones.  Where DP is a multiple of 32 (d = 32, 64) the
@@ -65,9 +81,10 @@ struct AttnCfg {
   static constexpr int ONES_T = VL ? 0 : DP / 32;          // tile / accumulator register that holds l = sum p (lanes hh = 0)
   static constexpr int ONES_I = 4 * ((DP % 32) >> 3);
   static_assert(DP % 16 == 0, "row DP must land on hh = 0, register 4 * (row / 8)");
-  static constexpr int KS = DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);  // K LDS row stride (odd number of 16-B slots)
+  static constexpr int KS = FP8 ? DP + 8 : DP * 2 + (((DP / 8) % 2 == 0) ? 16 : 0);  // K LDS row stride (bf16: odd number of 16-B slots)
+  static constexpr int VSB = FP8 ? VS8 : VS;               // V^T LDS row stride in bytes
   static constexpr int KBYTES = KV * KS;
-  static constexpr int VBYTES = DT * 32 * VS;
+  static constexpr int VBYTES = DT * 32 * VSB;
   static constexpr int TILE = KBYTES + VBYTES;
 };
 
@@ -75,7 +92,13 @@ struct AttnCfg {
 // works on tile g, and the groups' (max, sum, O^T) are merged through LDS at the end.  At N = 1000 / 252 with 8 x 8 heads a
 // query block per wave gives only 2 / 0.5 waves per SIMD; the split doubles the independent instruction streams that hide
 // the MFMA -> softmax -> MFMA dependency chain.
-template <int DP, int NW, int SP, bool PRESCALED>
+// FP8 (BASELINE config 5: "fp8 (e4m3) Q / K / V / P operands in K1 with fp32 accumulate"): the SAME kernel with one-byte LDS images --
+// Q / K / V^T arrive as bf16 (the QKV GEMM's outputs) and are converted while they are staged, the fragment reads are 8 bytes (K) and
+// 2 x 4 bytes (V^T), both MFMAs are v_mfma_f32_32x32x16_fp8_fp8 (the bf16 rate on gfx950: the non-scaled fp8 forms), P is scaled by 2^8
+// before its conversion (p <= 1 would sit in e4m3's subnormal range for long sequences; l carries the same factor, so it cancels).
+// Until round 4 this was a separate, older kernel (4 waves, no deferred rescale, predicated loads) and 4.6 us slower than bf16 at
+// N = 1000; as a variant of this one it inherits every structural improvement.
+template <int DP, int NW, int SP, bool PRESCALED, bool FP8 = false>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restrict__ q, int ldq,
                                                             const bf16* __restrict__ k, int ldk,
                                                             const bf16* __restrict__ vt, int vt_ld, long long vt_bs,
@@ -83,9 +106,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
                                                             bf16* __restrict__ out, int out_ld, float* __restrict__ lse,
                                                             const int* __restrict__ kv_len) {
   aldm_touch_kernargs<96>();                // 88 bytes of explicit arguments: both lines in one round (common.h)
-  using Cfg = AttnCfg<DP>;
+  using Cfg = AttnCfg<DP, FP8>;
   constexpr int T = 64 * NW;
-  constexpr int DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS;
+  constexpr int DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS, VS = Cfg::VSB;   // (VS shadows the bf16 stride: every use below is per-format)
+#ifndef ATTN_FP8_PBIAS
+#define ATTN_FP8_PBIAS 8.f
+#endif
+  constexpr float PBIAS = FP8 ? ATTN_FP8_PBIAS : 0.f;     // log2 of the factor P carries into its fp8 conversion
+  using frag_t = std::conditional_t<FP8, long, bf16x8>;
   constexpr int KCH = KV * (DP / 8);        // 16-B chunks in a K tile
   constexpr int VCH = DP * (KV / 8);        // 16-B chunks in a V^T tile
   constexpr int KPT = (KCH + T - 1) / T, VPT = (VCH + T - 1) / T;
@@ -138,17 +166,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     const int npad = DT * 32 - D;
     for (int i = tid; i < 2 * SP * npad * (VS / 8); i += T) {
       const int buf = i / (npad * (VS / 8)), rem = i - buf * npad * (VS / 8);
-      const unsigned fill = (!Cfg::VL && D + rem / (VS / 8) == DP) ? 0x3F803F80u : 0u;
+      const unsigned fill = (!Cfg::VL && D + rem / (VS / 8) == DP) ? (FP8 ? 0x38383838u : 0x3F803F80u) : 0u;   // 1.0 as bf16 / e4m3 pairs
       reinterpret_cast<uint2*>(Vs + buf * Cfg::VBYTES + D * VS)[rem] = make_uint2(fill, fill);
     }
   }
 
   // Q fragments (B operand): lane (r, hh) holds Q[q0 + r][16 ks + 8 hh .. +7]
-  bf16x8 qf[DK];
+  frag_t qf[DK];
 #pragma unroll
   for (int ks = 0; ks < DK; ++ks) {
     const int col = 16 * ks + 8 * hh;
-    qf[ks] = (q0 + r < N && col < D) ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + r) * ldq + col) : zero8;
+    const bf16x8 qv = (q0 + r < N && col < D) ? *reinterpret_cast<const bf16x8*>(qb + (long long)(q0 + r) * ldq + col) : zero8;
+    if constexpr (FP8) { const uint2 f = bf16x8_to_fp8(qv); qf[ks] = pack2(f.x, f.y); }
+    else qf[ks] = qv;
   }
 
   // two register sets: the loads of tile-group it+2 are issued at the top of iteration it and written to LDS at the bottom of
@@ -208,7 +238,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     for (int i = 0; i < KPT; ++i) {
       const int cidx = tid + i * T;
       const int row = cidx / (DP / 8), ch = cidx - row * (DP / 8);
-      if (cidx < KCH) *reinterpret_cast<bf16x8*>(Ks + (buf * SP + j) * Cfg::KBYTES + row * KS + ch * 16) = kreg[SET][j][i];
+      if (cidx < KCH) {
+        if constexpr (FP8) *reinterpret_cast<uint2*>(Ks + (buf * SP + j) * Cfg::KBYTES + row * KS + ch * 8) = bf16x8_to_fp8(kreg[SET][j][i]);
+        else *reinterpret_cast<bf16x8*>(Ks + (buf * SP + j) * Cfg::KBYTES + row * KS + ch * 16) = kreg[SET][j][i];
+      }
     }
    }
   };
@@ -227,11 +260,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll                                     //  p = 0 there, but those bytes are row padding / the next row, not zeros
           for (int e = 0; e < 8; ++e) if (kv0 + ch * 8 + e >= Nk) v[e] = (bf16)0.f;
         }
-        // rows are 136 B apart: 8-byte aligned only -> two 8-byte stores
-        uint2* dst = reinterpret_cast<uint2*>(Vs + (buf * SP + j) * Cfg::VBYTES + row * VS + ch * 16);
-        const uint4 u = __builtin_bit_cast(uint4, v);
-        dst[0] = make_uint2(u.x, u.y);
-        dst[1] = make_uint2(u.z, u.w);
+        if constexpr (FP8) {
+          *reinterpret_cast<uint2*>(Vs + (buf * SP + j) * Cfg::VBYTES + row * VS + ch * 8) = bf16x8_to_fp8(v);
+        } else {
+          // rows are 136 B apart: 8-byte aligned only -> two 8-byte stores
+          uint2* dst = reinterpret_cast<uint2*>(Vs + (buf * SP + j) * Cfg::VBYTES + row * VS + ch * 16);
+          const uint4 u = __builtin_bit_cast(uint4, v);
+          dst[0] = make_uint2(u.x, u.y);
+          dst[1] = make_uint2(u.z, u.w);
+        }
       }
     }
    }
@@ -271,10 +308,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + buf * Cfg::KBYTES + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
         // the first K-step reads its C operand from `minit` (-m_run in every row; zeros for unscaled scores) and writes a DIFFERENT
         // register block: no 16 v_mov per 32 keys to seed the accumulator
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? minit : s[sub], 0, 0, 0);
+        if constexpr (FP8) {
+          const uint2 kf = *reinterpret_cast<const uint2*>(Ks + buf * Cfg::KBYTES + (sub * 32 + r) * KS + 16 * ks + 8 * hh);
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pack2(kf.x, kf.y), qf[ks], ks == 0 ? minit : s[sub], 0, 0, 0);
+        } else {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + buf * Cfg::KBYTES + (sub * 32 + r) * KS + (16 * ks + 8 * hh) * 2);
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? minit : s[sub], 0, 0, 0);
+        }
       }
     }
   };
@@ -295,21 +337,30 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #ifdef ATTN_DIAG_NOMAX
     float mx = s[0][0];
 #else
-    float mx0 = max3f(s[0][0], s[0][1], s[0][2]), mx1 = max3f(s[1][0], s[1][1], s[1][2]);   // two independent chains
+    // (both chains START from a compiler-visible v_max_f32 over the last register of each MFMA result: max3f is inline asm, and the
+    //  compiler inserts the MFMA -> VALU wait states only in front of its OWN instructions; every asm instruction depends on these two)
+    float mx0 = fmaxf(s[0][0], s[1][15]), mx1 = fmaxf(s[1][0], s[0][15]);                    // two independent chains
 #pragma unroll
-    for (int i = 3; i < 15; i += 2) {
+    for (int i = 1; i < 15; i += 2) {
       mx0 = max3f(mx0, s[0][i], s[0][i + 1]);
       mx1 = max3f(mx1, s[1][i], s[1][i + 1]);
     }
-    float mx = max3f(mx0, mx1, fmaxf(s[0][15], s[1][15]));
-    {   // the other 32 keys of this query column sit in lane ^ 32: v_permlane32_swap (VALU) instead of an LDS round trip
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    float mx = fmaxf(mx0, mx1);
+    {   // the other 32 keys of this query column sit in lane ^ 32: v_permlane32_swap (VALU) instead of an LDS round trip.
+        // COMPILER PITFALL (round 4, found through the fp8 form): with __builtin_amdgcn_permlane32_swap the `fmaxf(sw[0], sw[1])` over
+        // the builtin's two results never reached the ISA -- only the swap's FIRST result was used (ROCm 7.2; an opaque copy of the second
+        // operand did not change that), so every column tracked the maximum of HALF its keys (lanes >= 32 took the lower half's).
+        // Harmless in bf16 (any reference point is a valid softmax shift and P stays in range), an overflow of e4m3's 448 in a quarter of
+        // the rows with fp8 operands.  The instruction is therefore written out, with the wait states its operands need.
+      float mxo = mx;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(mx), "+v"(mxo));
+      mx = fmaxf(mx, mxo);
     }
 #endif
     // excess of this tile's maximum over the running one, in the scaled (log2) domain
-    const float ex = PRESCALED ? mx : fmaf(mx, c, -m_run);
-    if (first || !__all(ex <= RESCALE_THR)) {
+    const float ex = PRESCALED ? (first ? mx : mx - PBIAS) : fmaf(mx, c, -m_run);
+    // (FP8: P x 2^8 must stay below e4m3's 448, so the maximum is tracked exactly -- no deferred rescale)
+    if (first || !__all(ex <= (FP8 ? 0.f : RESCALE_THR))) {
       const float delta = first ? ex : fmaxf(ex, 0.f);                  // the maximum never decreases after the first tile
       m_run += delta;
       if (!first) {
@@ -329,9 +380,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) s[sub][i] -= delta;
+          for (int i = 0; i < 16; ++i) s[sub][i] -= first ? delta - PBIAS : delta;   // (the first tile's scores came out without any bias)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) minit[i] = -m_run;
+        for (int i = 0; i < 16; ++i) minit[i] = PBIAS - m_run;    // (FP8: the 2^8 of P rides in the initial accumulator too)
       }
     }
     // ---- p = exp2(s'), O^T += V^T P^T (row DP of V^T is ones: l accumulates alongside; ML: one more MFMA against a register of ones).
@@ -340,14 +391,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     // instructions -- tools/micro/mfma_valu_gap.hip).  The barrier at the end of every tile keeps the SIMD's two waves in phase, so
     // nothing but the wave's own instruction stream fills those cycles: left to the scheduler, all 32 exponentials came first and
     // the MFMAs ran back to back behind them, pipe-bound in both waves at once.
-    bf16x8 pf[4];
-    auto vfrag = [&](int t, int s2) {
-      const char* vrow = Vs + buf * Cfg::VBYTES + (t * 32 + r) * VS + (16 * s2 + 4 * hh) * 2;
-      const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-      const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-      return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    frag_t pf[4];
+    auto vfrag = [&](int t, int s2) -> frag_t {
+      if constexpr (FP8) {                      // the lane's 8 keys = {16 s2 + 4 hh + 0..3, + 8..11}: two 4-byte reads
+        const char* vrow = Vs + buf * Cfg::VBYTES + (t * 32 + r) * VS + 16 * s2 + 4 * hh;
+        return pack2(*reinterpret_cast<const unsigned*>(vrow), *reinterpret_cast<const unsigned*>(vrow + 8));
+      } else {
+        const char* vrow = Vs + buf * Cfg::VBYTES + (t * 32 + r) * VS + (16 * s2 + 4 * hh) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+        return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
     };
-    bf16x8 vf[2][DT];
+    frag_t vf[2][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) vf[0][t] = vfrag(t, 0);
 #pragma unroll
@@ -357,23 +413,40 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll
         for (int t = 0; t < DT; ++t) vf[(s2 + 1) & 1][t] = vfrag(t, s2 + 1);   // next step's V^T fragments: requested before this step's exponentials
       }
+      int pw8[2] = {0, 0};                       // FP8: the step's 8 probabilities as e4m3 bytes
 #pragma unroll
       for (int i = 0; i < 8; i += 2) {
-        const float e0 = PRESCALED ? s[sub][i0 + i] : fmaf(s[sub][i0 + i], c, -m_run);
-        const float e1 = PRESCALED ? s[sub][i0 + i + 1] : fmaf(s[sub][i0 + i + 1], c, -m_run);
+        const float e0 = PRESCALED ? s[sub][i0 + i] : fmaf(s[sub][i0 + i], c, PBIAS - m_run);
+        const float e1 = PRESCALED ? s[sub][i0 + i + 1] : fmaf(s[sub][i0 + i + 1], c, PBIAS - m_run);
 #ifdef ATTN_DIAG_NOEXP
         const float p0 = e0, p1 = e1;
 #else
         const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
 #endif
+#ifdef ATTN_FP8_CLAMP
+        const float p0c = fminf(p0, 448.f), p1c = fminf(p1, 448.f);
+#define P0 p0c
+#define P1 p1c
+#else
+#define P0 p0
+#define P1 p1
+#endif
         if constexpr (Cfg::VL && !ML) l_run += p0 + p1;
-        pf[s2][i] = (bf16)p0;
-        pf[s2][i + 1] = (bf16)p1;
+        if constexpr (FP8) {
+          pw8[i >> 2] = (i & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(P0, P1, pw8[i >> 2], true) : __builtin_amdgcn_cvt_pk_fp8_f32(P0, P1, pw8[i >> 2], false);
+        } else {
+          pf[s2][i] = (bf16)p0;
+          pf[s2][i + 1] = (bf16)p1;
+        }
       }
+      if constexpr (FP8) pf[s2] = pack2((unsigned)pw8[0], (unsigned)pw8[1]);
       if (ATTN_FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2 & 1][t], pf[s2], o[t], 0, 0, 0);
-      if constexpr (ML) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[s2], lacc, 0, 0, 0);
+      for (int t = 0; t < DT; ++t) {
+        if constexpr (FP8) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf[s2 & 1][t], pf[s2], o[t], 0, 0, 0);
+        else o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2 & 1][t], pf[s2], o[t], 0, 0, 0);
+      }
+      if constexpr (ML && !FP8) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[s2], lacc, 0, 0, 0);
       if (ATTN_FENCE) __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -482,13 +555,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   }
 }
 
-template <int DP, int NW, int SP, bool PS>
+template <int DP, int NW, int SP, bool PS, bool FP8 = false>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
                 int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
-  using Cfg = AttnCfg<DP>;
-  auto kern = attention_kernel<DP, NW, SP, PS>;
-  constexpr int LDS = 2 * SP * Cfg::TILE;
-  static_assert(SP == 1 || (SP - 1) * (NW / SP) * (Cfg::DT * 16 + 2) * 256 <= LDS, "merge buffer must fit the staging area");
+  using Cfg = AttnCfg<DP, FP8>;
+  auto kern = attention_kernel<DP, NW, SP, PS, FP8>;
+  constexpr int MERGE = SP == 1 ? 0 : (SP - 1) * (NW / SP) * (Cfg::DT * 16 + 2) * 256;   // the key groups' (m, O^T, l) exchange re-uses the staging area
+  constexpr int LDS = 2 * SP * Cfg::TILE > MERGE ? 2 * SP * Cfg::TILE : MERGE;             // (one-byte images can be smaller than it)
   static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
   if (LDS > 48 * 1024)
     if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), LDS, &attr_done, "attention")) return rc;
@@ -498,7 +571,7 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, 
   return aldm_launch_status("attention");
 }
 
-template <int DP, bool PS>
+template <int DP, bool PS, bool FP8 = false>
 int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_bs, int B, int N,
                   int H, int D, float scale, void* out, int out_ld, float* lse, const int* kv_len, hipStream_t st) {
   // measured in a replayed graph: N = 1000 (d 32) 4 waves 24 us vs 2 waves 31; N = 252 (d 48) 4 waves 8.9 us vs 2 waves 9.4;
@@ -508,6 +581,15 @@ int launch_attn_d(const void* q, int ldq, const void* k, int ldk, const void* vt
   // N = 1000 with 4 heads 16.6 -> 14.6 us; at N = 1000 x 64 (batch, head) pairs the kernel is VALU-throughput-bound (softmax)
   // and the split only adds the merge: 22.9 -> 23.4 us, so the full-size case keeps one wave per query block
 #define ALDM_ATTN_ARGS q, ldq, k, ldk, vt, vt_ld, vt_bs, B, N, H, D, scale, out, out_ld, lse, kv_len, st
+  if constexpr (FP8) {                        // (the tuning overrides below are not instantiated for the fp8 form)
+    if (N >= 768) {
+      if ((long long)cdiv(N, 256) * H * B >= 256) return launch_attn<DP, 8, 1, PS, true>(ALDM_ATTN_ARGS);
+      return launch_attn<DP, 8, 2, PS, true>(ALDM_ATTN_ARGS);
+    }
+    if (N >= 192) return launch_attn<DP, 4, 2, PS, true>(ALDM_ATTN_ARGS);
+    if (N >= 64) return launch_attn<DP, 4, 1, PS, true>(ALDM_ATTN_ARGS);
+    return launch_attn<DP, 1, 1, PS, true>(ALDM_ATTN_ARGS);
+  }
   static const int force = getenv("ALDM_ATTN_CFG") ? atoi(getenv("ALDM_ATTN_CFG")) : 0;   // tuning aid: 10 * waves + key split
   if (force == 81) return launch_attn<DP, 8, 1, PS>(ALDM_ATTN_ARGS);
   if (force == 82) return launch_attn<DP, 8, 2, PS>(ALDM_ATTN_ARGS);
@@ -551,7 +633,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
-template <bool PS>
+template <bool PS, bool FP8 = false>
 static int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
                           long long vt_batch_stride, int B, int N, int H, int d, float scale, void* out, int out_ld,
                           float* lse, const int* kv_len, void* stream) {
@@ -560,7 +642,7 @@ static int attention_impl(const void* q, int ldq, const void* k, int ldk, const 
   ALDM_CHECK_ARG(d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0, "attention: d/ld must be multiples of 8");
   ALDM_CHECK_ARG(vt_ld >= ((N + 7) / 8) * 8, "attention: vt_ld %d too small for N %d", vt_ld, N);
   hipStream_t st = (hipStream_t)stream;
-#define ALDM_ATTN(DPV) return launch_attn_d<DPV, PS>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, kv_len, st)
+#define ALDM_ATTN(DPV) return launch_attn_d<DPV, PS, FP8>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, lse, kv_len, st)
   if (d <= 16) ALDM_ATTN(16);
   if (d <= 32) ALDM_ATTN(32);
   if (d <= 48) ALDM_ATTN(48);
@@ -583,6 +665,15 @@ extern "C" int aldm_attention_prescaled(const void* q, int ldq, const void* k, i
                                         long long vt_batch_stride, int B, int N, int H, int d, void* out, int out_ld,
                                         void* stream) {
   return attention_impl<true>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, 1.0f, out, out_ld, nullptr, nullptr, stream);
+}
+
+// BASELINE config 5: the same core with fp8 (OCP e4m3) Q / K / V / P MFMA operands and fp32 accumulation (attention_kernel<..., FP8>).
+// scale * log2(e) == 1 means Q is pre-scaled (the UNet folds d^-0.5 log2 e into to_q): the PRESCALED form, no per-score multiply.
+extern "C" int aldm_attention_fp8(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld, long long vt_batch_stride,
+                                  int B, int N, int H, int d, float scale, void* out, int out_ld, void* stream) {
+  if (fabsf(scale * 1.44269504088896340736f - 1.0f) < 1e-6f)
+    return attention_impl<true, true>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, 1.0f, out, out_ld, nullptr, nullptr, stream);
+  return attention_impl<false, true>(q, ldq, k, ldk, vt, vt_ld, vt_batch_stride, B, N, H, d, scale, out, out_ld, nullptr, nullptr, stream);
 }
 
 extern "C" int aldm_attention_lse(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_ld,
