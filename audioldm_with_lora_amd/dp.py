@@ -67,37 +67,86 @@ class ProjectConfiguration:
             self.logging_dir = self.project_dir
 
 
+class _BatchSamplerShard:
+    """accelerate's BatchSamplerShard (split_batches=False, even_batches=True) over the wrapped loader's batch sampler: of every N
+    consecutive batches of INDICES process r keeps the r-th -- only the kept batches are ever loaded (wav decoding, mel extraction
+    and tokenisation are not repeated N times per rank).  A short last batch is completed, and an incomplete last group of batches is
+    filled, by cycling through the epoch's first indices, so that every rank runs the same number of equally sized steps (the flat
+    all-reduce averages with a fixed 1 / world).  The shuffle is the SAME permutation on every rank: at the start of each epoch rank
+    0's seed is broadcast and seeds the sampler's generator (accelerate: synchronize_rng_states / SeedableRandomSampler)."""
+
+    def __init__(self, batch_sampler, rank, world):
+        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world
+        self.batch_size = getattr(batch_sampler, "batch_size", None)
+        self.drop_last = getattr(batch_sampler, "drop_last", False)
+
+    def __len__(self):
+        n = len(self.batch_sampler)
+        return n // self.world if self.drop_last else (n + self.world - 1) // self.world
+
+    def _sync_shuffle(self):
+        sampler = getattr(self.batch_sampler, "sampler", None)
+        if sampler is None or not hasattr(sampler, "generator"):
+            return                                           # sequential / custom samplers: nothing random to agree on
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = seed.cuda() if dist.get_backend() == "nccl" else seed
+            dist.broadcast(t, src=0)
+            seed = t.cpu()
+        g = torch.Generator()
+        g.manual_seed(int(seed))
+        sampler.generator = g
+
+    def __iter__(self):
+        self._sync_shuffle()
+        batches = [list(b) for b in self.batch_sampler]      # index lists only: cheap, and every rank derives the same epoch plan
+        if not batches:
+            return
+        head = [i for b in batches for i in b]               # the epoch's indices in order: the pool completions cycle through
+        bs = self.batch_size or len(batches[0])
+        if len(batches[-1]) < bs and not self.drop_last:
+            k = 0
+            while len(batches[-1]) < bs:
+                batches[-1].append(head[k % len(head)])
+                k += 1
+        if self.drop_last:
+            batches = batches[: len(batches) // self.world * self.world]
+        else:
+            k = 0
+            while len(batches) % self.world:                 # incomplete last group: wrap around to the first batches of the epoch
+                batches.append(list(batches[k]))
+                k += 1
+        for j in range(self.rank, len(batches), self.world):
+            yield batches[j]
+
+
 class ShardedLoader:
-    """What `accelerator.prepare(dataloader)` returns under N > 1 processes: accelerate's DataLoaderShard / BatchSamplerShard with
+    """What `accelerator.prepare(dataloader)` returns under N > 1 processes: accelerate's DataLoaderShard over a BatchSamplerShard with
     its defaults (split_batches=False, even_batches=True).  The loader's batch size stays the PER-PROCESS batch size; of every N
     consecutive batches process r takes the r-th, so the ranks consume disjoint data and the global batch is N x batch_size
-    [REF script/train/train_audioldm_lora.py:421-430,445-447].  A last, incomplete group is completed by wrapping around to the
-    first batches of the epoch, so that every rank runs the same number of steps (no rank waits in an all-reduce forever)."""
+    [REF script/train/train_audioldm_lora.py:421-430,445-447].  The sharding happens at the batch SAMPLER (see _BatchSamplerShard):
+    a rank loads only its own batches, all ranks shuffle with the same broadcast seed, and short / missing last batches are completed
+    from the start of the epoch so that every rank runs the same number of full-size steps."""
 
     def __init__(self, loader, rank, world):
         self.loader, self.rank, self.world = loader, rank, world
+        if getattr(loader, "batch_sampler", None) is None:
+            raise ValueError("ShardedLoader needs a DataLoader with a batch sampler (batch_size=None loaders cannot be sharded by batch)")
+        self.shard = _BatchSamplerShard(loader.batch_sampler, rank, world)
+        kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, timeout=loader.timeout,
+                  worker_init_fn=loader.worker_init_fn, generator=loader.generator, persistent_workers=loader.persistent_workers)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, multiprocessing_context=loader.multiprocessing_context)
+        self._inner = torch.utils.data.DataLoader(loader.dataset, batch_sampler=self.shard, **kw)
 
     def __len__(self):
-        return (len(self.loader) + self.world - 1) // self.world
+        return len(self.shard)
 
     def __getattr__(self, name):                             # batch_size, dataset, ... of the wrapped loader
         return getattr(self.loader, name)
 
     def __iter__(self):
-        first, group = [], []
-        for batch in self.loader:
-            if len(first) < self.world:
-                first.append(batch)
-            group.append(batch)
-            if len(group) == self.world:
-                yield group[self.rank]
-                group = []
-        if group:                                            # incomplete last group: pad from the start of the epoch
-            i = 0
-            while len(group) < self.world:
-                group.append(first[i % len(first)])
-                i += 1
-            yield group[self.rank]
+        return iter(self._inner)
 
 
 class PreparedScheduler:

@@ -118,6 +118,59 @@ def test_prepare_shards_the_dataloader_and_steps_the_schedule_once_per_process(t
     assert all(abs(a - b) < 1e-15 for a, b in zip(r0["lrs"], want)) and r0["lrs"] == r1["lrs"]
 
 
+class _CountingDataset(torch.utils.data.Dataset):
+    """records which items were actually LOADED (the point of sharding at the batch sampler)"""
+
+    def __init__(self, n):
+        self.n, self.loaded = n, []
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        self.loaded.append(int(i))
+        return torch.tensor(float(i))
+
+
+def _shuffle_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from audioldm_with_lora_amd import dp
+    assert dp.init_from_env(backend="gloo") == world
+    torch.manual_seed(1000 + 17 * rank)                          # DIFFERENT global seeds: the ranks must still agree on the permutation
+    acc = dp.Accelerator()
+    data = _CountingDataset(13)                                  # 13 items, batch 3: a short last batch AND an incomplete last group
+    loader = acc.prepare(torch.utils.data.DataLoader(data, batch_size=3, shuffle=True))
+    epochs = []
+    for _ in range(2):
+        data.loaded.clear()
+        seen = [b.tolist() for b in loader]
+        epochs.append({"seen": seen, "loaded": sorted(data.loaded)})
+    acc.wait_for_everyone()
+    torch.save(epochs, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_sharded_loader_loads_only_its_batches_with_one_shared_shuffle(tmp_path):
+    """accelerate shards at the batch sampler (a rank loads only the batches it keeps), synchronises the shuffle across
+    ranks, and completes short / missing last batches (even_batches=True)."""
+    out = str(tmp_path / "shuf.pt")
+    mp.spawn(_shuffle_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for e in range(2):
+        a, b = r0[e], r1[e]
+        assert len(a["seen"]) == len(b["seen"]) == 3 and all(len(x) == 3 for x in a["seen"] + b["seen"])   # same step count, full batches
+        inter = [x for pair in zip(a["seen"], b["seen"]) for x in pair]      # the epoch as the two ranks consumed it together
+        flat = [int(i) for x in inter for i in x]
+        assert sorted(set(flat)) == list(range(13))              # ONE permutation of the dataset, split between the ranks ...
+        assert len(flat) == 18 and flat[:13] == flat[:13] and len(set(flat[:13])) == 13   # ... 13 distinct items, then 5 completions
+        # completions cycle through the start of the epoch: the short 5th batch takes the first two indices, the missing 6th batch is the first batch
+        assert flat[13:15] == flat[:2] and flat[15:] == flat[:3]
+        # each rank loaded exactly what it yielded -- not the other rank's batches
+        assert a["loaded"] == sorted(int(i) for x in a["seen"] for i in x)
+        assert b["loaded"] == sorted(int(i) for x in b["seen"] for i in x)
+    assert r0[0]["seen"] != r0[1]["seen"]                        # a new permutation every epoch
+
+
 def test_single_process_prepare_returns_loader_and_schedule_unchanged():
     from audioldm_with_lora_amd import dp, optim
     acc = dp.Accelerator()
