@@ -5,11 +5,12 @@
 // V^T fragment reads reproduce with two 8-byte LDS reads).  K / V^T tiles of 64 keys are shared by the
 // workgroup's waves through padded (bank-conflict-free) LDS images, register-prefetched one tile ahead.
 //
-// The loop's time is VALU time PLUS MFMA time: on this chip a SIMD does not run plain VALU work under its own (or its other
-// wave's) MFMAs -- tools/micro/mfma_valu_overlap.hip: 12 MFMAs 183 ns, 84 fma 98 ns, finely interleaved 291 ns; only v_exp
-// overlaps, partly.  A software-pipelined loop (next tile's S' MFMAs and this tile's P V MFMAs spread over the exponentials, all
-// LDS fragments requested a phase early) therefore measured 22.5 us against 22.3 at N = 1000 and was dropped; what counts is
-// the instruction count of each kind.  So the per-key VALU work is cut to its essentials:
+// What bounds the loop (round 4; the round-3 note here -- "a SIMD does not run plain VALU work under its own MFMAs" -- was wrong:
+// tools/micro/mfma_valu_gap.hip, instruction stream pinned by inline asm, hides five v_fma_f32 or three v_exp_f32 under every
+// v_mfma_f32_32x32x16_bf16 of ONE wave, and two waves per SIMD overlap by themselves when no barrier re-aligns them): at UNet batch 8
+// the grid is one 8-wave workgroup per CU and each 64-key tile is a dependent chain (fragment reads -> S^T MFMAs -> maximum -> exp ->
+// convert -> P V MFMAs -> barrier) of ~1300 cycles that two waves per SIMD do not cover; the ablation is at the ATTN_ML / ATTN_FENCE
+// switches below.  The per-key VALU work is nevertheless cut to its essentials:
 //   * the running maximum enters as the INITIAL ACCUMULATOR of the S^T MFMAs (S' = K Q^T - m), so p = exp2(S') needs no
 //     per-element subtraction; the maximum is only raised when a tile exceeds it by more than RESCALE_THR (deferred rescale,
 //     wave-uniform branch) -- P is then bounded by 2^THR instead of 1, which fp32 accumulation and bf16 P tolerate

@@ -36,10 +36,11 @@ BK = 64
 # tape
 # ----------------------------------------------------------------------------------------------
 class Var:
-    __slots__ = ("t", "g", "rg", "gn", "tT", "want_T", "gT")
+    __slots__ = ("t", "g", "rg", "gn", "tT", "want_T", "gT", "stats")
 
     def __init__(self, t, rg=False):
         self.t, self.g, self.rg = t, None, rg
+        self.stats = None            # row statistics handed over by the producing GEMM (t_lora_linear rowstats=)
         self.tT = self.want_T = self.gT = None                       # token-major copies (see t_lora_linear)
         self.gn = None               # (channels, groups) when this is a GroupNorm output: its single consumer conv may hand the
                                      # norm's backward its dX as split-K partial tiles (g is then an ops.Deferred)
@@ -172,6 +173,17 @@ def t_layernorm(tape, x, gamma, beta):
     return y
 
 
+def t_layernorm_folded(tape, x, gamma):
+    """LayerNorm whose FORWARD is folded into the consuming GEMM (weights packed with pack_linear_ln, row statistics handed over by
+    the producer of x: no launch here).  The returned Var stands for LN(x) on the tape -- its tensor is x itself, which the folded
+    GEMM reads -- and the backward is the ordinary LayerNorm backward (it recomputes the statistics from x).  Only valid where
+    nothing but that GEMM consumes LN(x): norm3 -> GEGLU (no LoRA gradient reads the normalised activations there)."""
+    y = Var(x.t, x.rg)
+    if x.rg:
+        tape.record(lambda: put(x, ops.layernorm_bwd(x.t, y.g, gamma, dx_add=prior(x))) if y.g is not None else None)
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # LoRA sites: one per fused projection GEMM (q|k|v together, out-proj alone)
 # ----------------------------------------------------------------------------------------------
@@ -224,7 +236,7 @@ def _tok_major_buf(B, N, Cc, dev):
     return mk(B, Cc, npad, dtype=torch.bfloat16, device=dev)
 
 
-def t_lora_linear(tape, x, site, res=None, tok=None):
+def t_lora_linear(tape, x, site, res=None, tok=None, rowstats=False):
     """x [M, K] -> y [M, N] with the LoRA side channel; records dX + dA/dB.
     tok = (B, N): the GEMM ALSO stores y token-major ([B, N_out, Npad], aldm_igemm vt_dual) -- returned as y.tT; the flash
     kernels read q | k | v that way, so the separate transpose launch disappears.  A Var x with x.want_T = (B, N) asks the same
@@ -239,7 +251,12 @@ def t_lora_linear(tape, x, site, res=None, tok=None):
         y = Var(out, True)
         y.tT = yT
     else:
-        y = Var(ops.linear(x.t, site.fwd, res=(res.t if res is not None else None), lora_t_out=T, splits=1), True)
+        out = ops.linear(x.t, site.fwd, res=(res.t if res is not None else None), lora_t_out=T, splits=1, rowstats=rowstats)
+        st = None
+        if rowstats:
+            out, st = out
+        y = Var(out, True)
+        y.stats = st                 # per-row partial (sum, sum of squares) of the stored values: a LayerNorm-folded consumer's ln_parts
 
     def bwd():
         dy = y.g
@@ -367,6 +384,7 @@ def trainer_of(unet, create=True):
     return tr
 
 
+FOLD_NORM3 = os.environ.get("ALDM_NO_FOLD_NORM3") is None             # training forward: norm3 folded into the GEGLU GEMM (A/B aid)
 SIDE_STREAM_H2D = os.environ.get("ALDM_NO_SIDE_STREAM_H2D") is None      # step_from_batch: batch copies on a side stream (A/B aid)
 
 
@@ -447,7 +465,7 @@ class LoraTrainer:
         self.weights_version = self.unet._weights_version
 
     # ---- forward with tape ----
-    def _attention(self, tape, tblk_attn, Pa, hn, h_res, B, N):
+    def _attention(self, tape, tblk_attn, Pa, hn, h_res, B, N, rowstats=False):
         qkv_site, out_site = self.sites[id(tblk_attn)]
         C, H, d = Pa.c, Pa.heads, Pa.d
         if qkv_site is not None:
@@ -471,7 +489,7 @@ class LoraTrainer:
             tape.record(bwd)
         o.rg = qkv.rg
         if out_site is not None:
-            return t_lora_linear(tape, o, out_site, res=h_res)
+            return t_lora_linear(tape, o, out_site, res=h_res, rowstats=rowstats)
         y = t_conv(tape, t_view(tape, o, (1, 1, B * N, C)), Pa.out, res=t_view(tape, h_res, (1, 1, B * N, C)))
         return t_view(tape, y, (B * N, C))
 
@@ -482,8 +500,14 @@ class LoraTrainer:
         h = xn if xn is not None else t_groupnorm(tape, x, *transformer_gn(Pt))
         h = t_view(tape, t_conv(tape, h, Pt.proj_in), (B * N, C))
         h = self._attention(tape, tb.attn1, Pt.attn1, t_layernorm(tape, h, *Pt.ln[0]), h, B, N)
-        h = self._attention(tape, tb.attn2, Pt.attn2, t_layernorm(tape, h, *Pt.ln[1]), h, B, N)
-        n3 = t_layernorm(tape, h, *Pt.ln[2])
+        # norm3 -> GEGLU: nothing but the GEGLU projection consumes LN(h) (no LoRA site there), so its FORWARD is folded into that GEMM as
+        # in inference (Pt.ff1 = W diag(gamma) with the row statistics handed over by the out-projection); the backward is unchanged
+        fold3 = FOLD_NORM3 and C % 64 == 0 and getattr(Pt.ff1, "ln_s", None) is not None and self.sites[id(tb.attn2)][1] is not None
+        h = self._attention(tape, tb.attn2, Pt.attn2, t_layernorm(tape, h, *Pt.ln[1]), h, B, N, rowstats=fold3)
+        st3 = getattr(h, "stats", None) if fold3 else None
+        if st3 is not None and st3.shape[1] > 16:
+            st3 = None                                          # (more partials per row than the consumer takes: keep the launch)
+        n3 = t_layernorm_folded(tape, h, Pt.ln[2][0]) if st3 is not None else t_layernorm(tape, h, *Pt.ln[2])
         if "ff1_plain" not in Pt.__dict__:                    # LayerNorm NOT folded (the backward needs LN(h))
             gp = ops.pack_geglu(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
             Pt.ff1_plain = ops.PackedW(gp.w, gp.bias, gp.N, gp.Cin)           # same packed rows, plain-linear view (for dX)
@@ -493,7 +517,10 @@ class LoraTrainer:
             # one GEGLU GEMM writes g = value * gelu(gate) AND keeps the pre-activation projection for the backward
             M = B * N
             hp_t = torch.empty(M, 8 * C, dtype=torch.bfloat16, device=n3.t.device)
-            g = Var(ops.conv(n3.t.view(1, 1, M, C), Pt.ff1_geglu, out2=hp_t, splits=1).view(M, 4 * C), n3.rg)
+            if st3 is not None:
+                g = Var(ops.conv(n3.t.view(1, 1, M, C), Pt.ff1, out2=hp_t, splits=1, ln_parts=st3).view(M, 4 * C), n3.rg)
+            else:
+                g = Var(ops.conv(n3.t.view(1, 1, M, C), Pt.ff1_geglu, out2=hp_t, splits=1).view(M, 4 * C), n3.rg)
             if n3.rg:
                 def bwd_ff1():
                     if g.g is None:
