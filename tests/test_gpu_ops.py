@@ -601,6 +601,24 @@ def test_conv1d_to_one_channel_with_tanh(ops, B, T, C, K):
     close(got, want, rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("M_hw,Cin,Cout,splits,tile", [((32, 2), 640, 640, 6, 4), ((63, 4), 384, 384, 1, 2), ((125, 8), 256, 256, 2, 3), ((32, 2), 128, 1280, 1, 2)])
+def test_xcd_map_changes_speed_only(ops, monkeypatch, M_hw, Cin, Cout, splits, tile):
+    """aldm_igemm_t.xcd_map: the work-item -> XCD order (activation- or weight-stationary, auto) is a permutation of which workgroup
+    computes which (M-tile, N-tile, K-split): every order gives bit-identical results, for split-K (partials summed in split order by
+    the reduce) and unsplit launches, at the UNet's low-resolution shapes (8 images)."""
+    g = torch.Generator().manual_seed(5 + Cin)
+    H, W = M_hw
+    x = nhwc(bf(torch.randn(8, Cin, H, W, generator=g)))
+    pw = ops.pack_conv((torch.randn(Cout, Cin, 3, 3, generator=g) / 40).to(DEV), torch.randn(Cout, generator=g).to(DEV))
+    outs = []
+    for mode in (0, 1, 2):
+        monkeypatch.setattr(ops, "XCD_MAP", mode)
+        outs.append(ops.conv(x, pw, pad=(1, 1), splits=splits, tile=tile).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    want = F.conv2d(to_nchw(x), pw.w[:, :9 * Cin].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).float().cpu(), pw.bias.cpu(), padding=1)
+    close(to_nchw(outs[0]), want, rtol=2e-2)
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])
