@@ -201,7 +201,7 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     return max(2, min(want, fit))
 
 
-TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128)}
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64)}
 HALO_ROWS = {7: 320, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip; 128x128: three or five DMA passes)
 
 
@@ -265,7 +265,8 @@ class Tuner:
         default = heuristic_cfg(M, pw, ktiles, can_split, fast_path, has_vt, forced_splits)
         cands = []
         for t in [2, 3, 1, 4] + ([6] if (fast_path and not has_vt and ktiles >= 8) else []) + (
-                [9] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M >= 32768 and pw.N % 128 == 0) else []):
+                [9] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M >= 32768 and pw.N % 128 == 0) else []) + (
+                [10, 11] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M <= 8192) else []):
             bm, bn = TILE_DIMS[t]
             if has_vt and a.vt_col0 % bn:
                 continue
@@ -335,7 +336,7 @@ def save_tuned(path=TUNED_PATH):
                    "igemm": {k: list(v) for k, v in sorted(TUNED.items())}}, f, indent=0)
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event, site) per C-ABI call.
 # Events are recorded on the stream the kernel is launched on.  SITE tags the launches of one fused-LoRA attention module

@@ -137,7 +137,9 @@ enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE
        /* 3x3 / stride-1 / pad-1 convs only: the workgroup keeps the input halo of BM/OW image rows in LDS and reads the
           nine taps from it (csrc/igemm_halo.hip); needs Cin % 64 == 0, BM % OW == 0, no split-K / LoRA / V^T */
        ALDM_TILE_HALO_128x128 = 7, ALDM_TILE_HALO_64x128 = 8,
-       ALDM_TILE_256x128_W8 = 9 /* 8-wave workgroup, 64x64 per wave: big-M plain convolutions (VAE, vocoder) */ };
+       ALDM_TILE_256x128_W8 = 9 /* 8-wave workgroup, 64x64 per wave: big-M plain convolutions (VAE, vocoder) */,
+       ALDM_TILE_64x128_W8 = 10, ALDM_TILE_128x64_W8 = 11 /* 8-wave forms of the small tiles: two waves per SIMD where the grid is ~one
+          workgroup per CU (split-K convolutions of the low-resolution levels); LDS-DMA path, no LoRA / V^T */ };
 
 int aldm_igemm(const aldm_igemm_t* p, void* stream);
 size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p);

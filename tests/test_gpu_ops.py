@@ -619,6 +619,18 @@ def test_xcd_map_changes_speed_only(ops, monkeypatch, M_hw, Cin, Cout, splits, t
     close(to_nchw(outs[0]), want, rtol=2e-2)
 
 
+@pytest.mark.parametrize("tile,splits,ring", [(10, 1, 3), (10, 6, 3), (11, 1, 2), (11, 4, 4)])
+def test_conv3x3_eight_wave_small_tiles(ops, tile, splits, ring):
+    """the 8-wave forms of the 64x128 / 128x64 tiles (two waves per SIMD at ~one workgroup per CU): same results as torch, split-K or not"""
+    g = torch.Generator().manual_seed(60 + tile)
+    x, x2 = bf(torch.randn(8, 128, 32, 2, generator=g)), bf(torch.randn(8, 64, 32, 2, generator=g))
+    w, b = bf(torch.randn(320, 192, 3, 3, generator=g) * 0.03), torch.randn(320, generator=g)
+    r = bf(torch.randn(8, 320, 32, 2, generator=g))
+    want = F.conv2d(torch.cat([x, x2], 1), w, b, padding=1) + r
+    y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=tile, ring=ring, splits=splits)
+    close(to_nchw(y), want)
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])

@@ -1,0 +1,36 @@
+"""A/B of the 8-wave small tiles (10: 64x128w8, 11: 128x64w8) against the 4-wave ones on the split-K convolutions of the UNet's low-resolution
+levels, in a replayed graph with rotating weights (cold weight stream, as in the step).  usage: python tools/bench_w8.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audioldm_with_lora_amd import ops
+
+def run(name, B, H, W, Cin, Cout, cfgs, nrot=8):
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda() for _ in range(nrot)]
+    pws = [ops.pack_conv((torch.randn(Cout, Cin, 3, 3, generator=g) / 50).cuda(), torch.zeros(Cout).cuda()) for _ in range(nrot)]
+    ref = None
+    for (tile, ring, sp) in cfgs:
+        try:
+            y = ops.conv(xs[0], pws[0], pad=(1, 1), tile=tile, ring=ring, splits=sp)
+        except Exception as e:
+            print(f"{name} tile {tile} ring {ring} splits {sp}: {str(e)[:80]}"); continue
+        if ref is None:
+            ref = y.clone()
+        same = bool(torch.equal(y, ref)) or float((y.float() - ref.float()).abs().max()) < 2 ** -6 * float(ref.float().abs().max())
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for r in range(3):
+                for i in range(nrot):
+                    ops.conv(xs[i], pws[i], pad=(1, 1), tile=tile, ring=ring, splits=sp)
+        gr.replay(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / (3 * nrot))
+        print(f"{name} tile {ops.TILE_NAMES[tile]:10s} ring {ring} splits {sp:2d}: {best * 1e3:7.2f} us (conv + reduce){'' if same else '  MISMATCH'}", flush=True)
+
+run("M512 N640 K5760", 8, 32, 2, 640, 640, [(4, 3, 6), (4, 4, 6), (10, 3, 6), (10, 4, 6), (10, 3, 4), (10, 3, 8), (10, 3, 12), (3, 3, 6), (11, 3, 6), (11, 4, 6), (11, 3, 12), (2, 3, 4), (1, 2, 12)])
+run("M2016 N384 K3456", 8, 63, 4, 384, 384, [(2, 3, 4), (4, 3, 4), (10, 3, 4), (10, 4, 4), (10, 3, 6), (10, 3, 3), (11, 3, 4), (11, 3, 6), (3, 3, 4)])
+run("M2016 N384 K9216(C1024)", 8, 63, 4, 1024, 384, [(3, 3, 8), (11, 3, 8), (10, 3, 8), (11, 4, 8), (10, 3, 6), (11, 3, 12)])
+run("M8000 N256 K2304", 8, 125, 8, 256, 256, [(2, 2, 1), (4, 3, 2), (10, 3, 2), (10, 3, 1), (11, 3, 1), (11, 3, 2)])
