@@ -225,6 +225,9 @@ TUNER = None
 if os.path.exists(TUNED_PATH) and os.environ.get("ALDM_NO_TUNED") != "1":
     with open(TUNED_PATH) as _f:
         TUNED = {k: tuple(v) for k, v in json.load(_f)["igemm"].items()}
+if os.environ.get("ALDM_TUNED_PATCH"):                           # A/B aid: a JSON {key: [tile, ring, splits]} laid over the table
+    with open(os.environ["ALDM_TUNED_PATCH"]) as _f:
+        TUNED.update({k: tuple(v) for k, v in json.load(_f).items()})
 TUNED_LEGACY_KEYS = any(" k3x3 " in k and " ow" not in k for k in TUNED)
 
 
