@@ -39,6 +39,10 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr int W_PASSES = BN / RPP;                    // weight-tile DMA instructions per thread per tap
   constexpr int D = S - 1;                              // taps in flight ahead of the MFMAs
+  // (measured in the replayed step, round 4: with waves 4-7 issuing behind their MFMAs the level-0 launches took +1.0 .. +4.3 us
+  //  (24.0 -> 25.6, 54.9 -> 59.1 us) -- the nine taps of a chunk are short items and the late issue costs the ring its lead; the
+  //  generic 8-wave tile gains 2-3 % from the same stagger.  Off here.)
+  constexpr bool STAGGER = false;
   constexpr int HALO_BYTES = HP * RPP * 128;
   constexpr int BSTAGE = BN * 128;
   constexpr unsigned OOB = 0x80000000u;
@@ -228,8 +232,11 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
         }
       }
       __builtin_amdgcn_s_barrier();
-      issue(item + D, st_fill);
+      // (STAGGER as in igemm_pipe_kernel: waves 4-7 issue the next item's DMA behind their MFMAs, so that the two waves of a SIMD are
+      //  not both in the DMA issue and then both on the matrix pipe)
+      if (!(STAGGER && wave >= 4)) issue(item + D, st_fill);
       mma_tap(Hs + (c_c & 1) * HALO_BYTES, Bring + st * BSTAGE, c_dy * HW2 + c_dx);
+      if (STAGGER && wave >= 4) issue(item + D, st_fill);
       st = (st + 1 == S) ? 0 : st + 1;
       st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
       ++c_tap;
