@@ -11,6 +11,7 @@ int aldm_launch_tile_64x128(const IgemmDev& d, int Rp, bool vt, int ring, hipStr
 int aldm_launch_tile_64x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_128x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_256x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_256x128ws(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_64x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_128x64w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_halo(const IgemmDev& d, int tile, int ring, hipStream_t st);
@@ -164,6 +165,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_64x64: rc = aldm_launch_tile_64x64(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_256x128_W8: rc = aldm_launch_tile_256x128w8(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_256x128_WS: rc = aldm_launch_tile_256x128ws(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_64x128_W8: rc = aldm_launch_tile_64x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_128x64_W8: rc = aldm_launch_tile_128x64w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_HALO_128x128:

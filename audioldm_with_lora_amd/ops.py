@@ -193,6 +193,8 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     they take the deepest ring that fits; big grids gain nothing past 2-3."""
     if tile in (6, 9):
         return 2
+    if tile == 12:
+        return 3
     stage = (bm + bn + rp) * 128
     extra = (bn * 128 if rp else 0) + 2 * bm * 4
     per_cu = min(8, max(1, math.ceil(nwg / 256)))
@@ -201,7 +203,7 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     return max(2, min(want, fit))
 
 
-TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64)}
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64), 12: (256, 128)}
 HALO_ROWS = {7: 320, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip; 128x128: three or five DMA passes)
 
 
@@ -268,7 +270,8 @@ class Tuner:
         default = heuristic_cfg(M, pw, ktiles, can_split, fast_path, has_vt, forced_splits)
         cands = []
         for t in [2, 3, 1, 4] + ([6] if (fast_path and not has_vt and ktiles >= 8) else []) + (
-                [9] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M >= 32768 and pw.N % 128 == 0) else []) + (
+                [9, 12] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M >= 32768 and pw.N % 128 == 0 and pw.ln_s is None
+                            and not pw.geglu and not pw.Cext) else []) + (
                 [10, 11] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M <= 8192) else []):
             bm, bn = TILE_DIMS[t]
             if has_vt and a.vt_col0 % bn:
@@ -279,7 +282,7 @@ class Tuner:
                 sp_list += [sp for sp in (2, 3, 4, 6, 8, 12, 16)
                             if sp <= ktiles // 2 and base * sp <= 2560 and sp * M * pw.N * 4 <= (1 << 28)]
             for sp in sp_list:
-                for rg in ((2, 3) if t in (6, 9) else (2, 3, 4)):
+                for rg in ((3,) if t == 12 else (2, 3) if t in (6, 9) else (2, 3, 4)):
                     cands.append((t, rg, sp))
         if forced_splits in (None, 1):
             cands += [(t, rg, 1) for t in halo for rg in (2, 3, 4)]
@@ -339,7 +342,7 @@ def save_tuned(path=TUNED_PATH):
                    "igemm": {k: list(v) for k, v in sorted(TUNED.items())}}, f, indent=0)
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8", 12: "256x128ws"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event, site) per C-ABI call.
 # Events are recorded on the stream the kernel is launched on.  SITE tags the launches of one fused-LoRA attention module

@@ -631,6 +631,41 @@ def test_conv3x3_eight_wave_small_tiles(ops, tile, splits, ring):
     close(to_nchw(y), want)
 
 
+@pytest.mark.parametrize("kind", ["plain", "two_src_res", "upsample", "splitk", "act_out2", "conv1d_dil"])
+def test_conv_wave_specialised_tile(ops, kind):
+    """tile 12 (csrc/igemm_ws.hip): 8 compute waves + 4 loader waves feeding the LDS-DMA ring -- same results as torch for every launch
+    form the big-M convolutions use (two sources + residual, nearest up-sampling, split-K, activation epilogue with a second output,
+    dilated 1-D taps), ragged M (not a multiple of 256) and N = 128 / 256."""
+    g = torch.Generator().manual_seed(120)
+    if kind == "conv1d_dil":
+        x = bf(torch.randn(2, 128, 1, 1500, generator=g))
+        w, b = bf(torch.randn(128, 128, 1, 7, generator=g) * 0.04), torch.randn(128, generator=g)
+        want = F.conv2d(x, w, b, padding=(0, 9), dilation=(1, 3))
+        y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), pad=(0, 9), dil=(1, 3), tile=12)
+        close(to_nchw(y), want)
+        return
+    x = bf(torch.randn(2, 128, 37, 16, generator=g))
+    w, b = bf(torch.randn(256, 128, 3, 3, generator=g) * 0.04), torch.randn(256, generator=g)
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    if kind == "plain":
+        close(to_nchw(ops.conv(nhwc(x), pw, pad=(1, 1), tile=12)), F.conv2d(x, w, b, padding=1))
+    elif kind == "two_src_res":
+        x1, x2 = x[:, :64].contiguous(), x[:, 64:].contiguous()
+        r = bf(torch.randn(2, 256, 37, 16, generator=g))
+        close(to_nchw(ops.conv(nhwc(x1), pw, x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=12)), F.conv2d(x, w, b, padding=1) + r)
+    elif kind == "upsample":
+        want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+        close(to_nchw(ops.conv(nhwc(x), pw, pad=(1, 1), up_size=(74, 32), tile=12)), want)
+    elif kind == "splitk":
+        close(to_nchw(ops.conv(nhwc(x), pw, pad=(1, 1), tile=12, splits=3)), F.conv2d(x, w, b, padding=1))
+    else:
+        out2 = torch.empty(2, 37, 16, 256, dtype=torch.bfloat16, device=DEV)
+        y = ops.conv(nhwc(x), pw, pad=(1, 1), tile=12, out2=out2, post_act=ops.ACT_LRELU, post_slope=0.1)
+        want = F.conv2d(x, w, b, padding=1)
+        close(to_nchw(y), want)
+        close(to_nchw(out2), F.leaky_relu(want, 0.1))
+
+
 def test_elementwise(ops):
     g = torch.Generator().manual_seed(11)
     t = torch.tensor([996.0, 1.0, 501.0])
