@@ -12,6 +12,8 @@ int aldm_launch_tile_64x64(const IgemmDev& d, int Rp, bool vt, int ring, hipStre
 int aldm_launch_tile_128x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_256x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_256x128ws(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_64x128ws(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
+int aldm_launch_tile_128x64ws(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_64x128w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_tile_128x64w8(const IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st);
 int aldm_launch_halo(const IgemmDev& d, int tile, int ring, hipStream_t st);
@@ -166,6 +168,8 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_128x128_W8: rc = aldm_launch_tile_128x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_256x128_W8: rc = aldm_launch_tile_256x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_256x128_WS: rc = aldm_launch_tile_256x128ws(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_64x128_WS: rc = aldm_launch_tile_64x128ws(d, p->Rp, vt, p->ring, st); break;
+    case ALDM_TILE_128x64_WS: rc = aldm_launch_tile_128x64ws(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_64x128_W8: rc = aldm_launch_tile_64x128w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_128x64_W8: rc = aldm_launch_tile_128x64w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_HALO_128x128:

@@ -18,21 +18,25 @@
 
 namespace aldm_igemm_detail {
 
-template <int S, int EPI>
-__global__ __launch_bounds__(768) void igemm_ws_kernel(const IgemmDev p) {
+// The same split pays on the SMALL tiles of the UNet's 252- / 64-token levels (round 4, second half): there the grid is ~one workgroup per
+// CU, a K-tile costs a wave ~420 cycles of stalled DMA issue + ~280 of fragment reads and MFMAs + the barrier, and neither a second
+// wave per SIMD nor a stagger hid one behind the other -- because every wave still had to issue its share of the DMA.
+// With 4 compute waves + NL loader waves the K-tile costs max(DMA, MFMA): instantiated as 64x128 and 128x64 (+ the fused 1x1
+// second-source segment those levels' conv2 launches carry).
+template <int BM, int BN, int WM, int WN, int NL, int S, int EPI>
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(IgemmDev)>();
-  constexpr int BM = 256, BN = 128, WM = 4, WN = 2;
-  constexpr int NTC = 512, NTL = 256;                  // compute / loader threads
-  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 4 x 4 MFMA tiles per compute wave
-  constexpr int RPP = NTL / 8;                         // tile rows covered by one DMA pass of the loader waves (32)
+  constexpr int NTC = 64 * WM * WN, NTL = 64 * NL;     // compute / loader threads
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // MFMA tiles per compute wave
+  constexpr int RPP = NTL / 8;                         // tile rows covered by one DMA pass of the loader waves
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be whole DMA passes of the loader waves");
   constexpr int A_PASSES = BM / RPP, W_PASSES = BN / RPP;
-  constexpr int L = A_PASSES + W_PASSES;               // LDS-DMA instructions per loader thread per K-tile (12)
+  constexpr int L = A_PASSES + W_PASSES;               // LDS-DMA instructions per loader thread per K-tile
   constexpr int D = S - 1;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr unsigned OOB = 0x80000000u;
   static_assert((D - 1) * L < 64, "vmcnt immediate");
-  static_assert(S * STAGE >= EpiCfg<BM, BN>::BYTES, "the epilogue image re-uses the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [S][ A: BM x 128 B | B: BN x 128 B ]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -52,10 +56,11 @@ __global__ __launch_bounds__(768) void igemm_ws_kernel(const IgemmDev p) {
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
     const int rbase = lt >> 3;
     const int kchunk = (lt & 7) ^ ((rbase >> 1) & 7);   // the swizzle's inverse image: applied on the SOURCE chunk (see igemm_pipe_kernel)
-    int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES];
+    int a_pix0[A_PASSES], a_ih0[A_PASSES], a_iw0[A_PASSES], a_m[A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < A_PASSES; ++ps) {
       const int m = min(m0 + rbase + RPP * ps, p.M - 1);
+      a_m[ps] = m;                                      // the fused 1x1 segment reads output pixel m of x3 | x4
       const int b = fdiv(m, p.fd_ohw);
       const int pix = m - b * p.OHW;
       const int oh = fdiv(pix, p.fd_ow), ow = pix - oh * p.OW;
@@ -69,25 +74,38 @@ __global__ __launch_bounds__(768) void igemm_ws_kernel(const IgemmDev p) {
       const int row = min(n0 + rbase + RPP * ps, p.N - 1);
       b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
     }
-    int s_kh, s_kw, s_c0;                               // scalar K cursor (tap, channel)
+    // scalar K cursor (tap, channel); past the last filter tap (s_kh == KH) lies the optional fused 1x1 segment over x3 | x4
+    int s_kh, s_kw, s_c0;
     {
-      const int k = kt0 * BK;
-      const int tap = fdiv(k, p.fd_ctot);
-      s_c0 = k - tap * p.Ctot;
-      s_kh = fdiv(tap, p.fd_kw);
-      s_kw = tap - s_kh * p.KW;
+      const int k = kt0 * BK, kmain = p.KH * p.KW * p.Ctot;
+      if (k >= kmain && p.C3tot > 0) {
+        s_kh = p.KH; s_kw = 0; s_c0 = k - kmain;
+      } else {
+        const int tap = fdiv(k, p.fd_ctot);
+        s_c0 = k - tap * p.Ctot;
+        s_kh = fdiv(tap, p.fd_kw);
+        s_kw = tap - s_kh * p.KW;
+      }
     }
-    const int k_cin = p.Cin, k_cin2 = p.Cin2, k_ctot = p.Ctot;
+    const int k_cin = p.Cin, k_cin2 = p.Cin2, k_ctot = p.Ctot, k_cin3 = p.Cin3, k_cin4 = p.Cin4, k_c3tot = p.C3tot;
     bool s_fresh = true;
     unsigned cur_off[A_PASSES];
     int a_soff = 0, b_soff = kt0 * BK * 2;
     const int IHv = p.UH > 0 ? p.UH : p.IH, IWv = p.UW > 0 ? p.UW : p.IW;
 
     auto issue = [&](int kt, int stage) {
-      char* sbase = smem + stage * STAGE + lwave * 1024;   // + pass * 4096: this wave's 8 rows of the pass
+      char* sbase = smem + stage * STAGE + lwave * 1024;   // + pass * RPP * 128: this wave's 8 rows of the pass
       const bool live = kt < kt1;
-      const bool src2 = s_c0 >= k_cin;
+      const bool ext = s_kh >= p.KH;                    // (scalar) inside the fused 1x1 segment
+      const int cA = ext ? k_cin3 : k_cin;
+      const bool src2 = s_c0 >= cA;
       if (live) {
+        if (s_fresh && ext) {
+          const int Cs = src2 ? k_cin4 : k_cin3;
+#pragma unroll
+          for (int ps = 0; ps < A_PASSES; ++ps) cur_off[ps] = (unsigned)a_m[ps] * (unsigned)(Cs * 2) + kchunk * 16;
+          s_fresh = false;
+        }
         if (s_fresh) {
           const int Cs = src2 ? k_cin2 : k_cin;
           const int dh = s_kh * p.dh, dw = s_kw * p.dw;
@@ -108,10 +126,15 @@ __global__ __launch_bounds__(768) void igemm_ws_kernel(const IgemmDev p) {
           }
           s_fresh = false;
         }
-        a_soff = (s_c0 - (src2 ? k_cin : 0)) * 2;
+        a_soff = (s_c0 - (src2 ? cA : 0)) * 2;
         b_soff = kt * BK * 2;
       }
-      if (src2) {
+      if (ext) {   // descriptors built on the spot (transient SGPRs), as in igemm_pipe_kernel
+        const __amdgpu_buffer_rsrc_t rs_e = src2 ? make_rsrc(p.x4, p.x4_bytes) : make_rsrc(p.x3, p.x3_bytes);
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, live ? cur_off[ps] : OOB, a_soff, 0, 0);
+      } else if (src2) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, live ? cur_off[ps] : OOB, a_soff, 0, 0);
@@ -125,8 +148,8 @@ __global__ __launch_bounds__(768) void igemm_ws_kernel(const IgemmDev p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * 128 + ps * (RPP * 128)), 16, live ? b_off[ps] : OOB, b_soff, 0, 0);
       if (live) {   // advance the scalar cursor by one K-tile
         s_c0 += BK;
-        if (s_c0 == k_cin && k_cin2 > 0) s_fresh = true;
-        if (s_c0 >= k_ctot) {
+        if (s_c0 == cA && (ext ? k_cin4 : k_cin2) > 0) s_fresh = true;
+        if (s_c0 >= (ext ? k_c3tot : k_ctot)) {
           s_c0 = 0;
           s_fresh = true;
           if (++s_kw == p.KW) { s_kw = 0; ++s_kh; }
@@ -187,14 +210,13 @@ __global__ __launch_bounds__(768) void igemm_ws_kernel(const IgemmDev p) {
 #endif
 }
 
-template <int S, int EPI>
+template <int BM, int BN, int WM, int WN, int NL, int S, int EPI>
 int launch_ws(const IgemmDev& d, hipStream_t st) {
-  constexpr int BM = 256, BN = 128;
   constexpr size_t ring = (size_t)S * (BM + BN) * 128;
   constexpr size_t lds = (ring > (size_t)EpiCfg<BM, BN>::BYTES ? ring : (size_t)EpiCfg<BM, BN>::BYTES) + 2 * BM * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static unsigned long long attr_done = 0;
-  auto kern = igemm_ws_kernel<S, EPI>;
+  auto kern = igemm_ws_kernel<BM, BN, WM, WN, NL, S, EPI>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_ws")) return rc;
   if ((d.qstat || d.rowstat) && d.N % BN != 0) {
     aldm_set_error("igemm: qstat_out / rowstat_out need Cout %d to be a multiple of the tile width %d", d.N, BN);
@@ -207,22 +229,45 @@ int launch_ws(const IgemmDev& d, hipStream_t st) {
   dd.fd_tiles_m = make_fastdiv((unsigned)dd.tiles_m);
   dd.fd_splits = make_fastdiv((unsigned)d.splits);
   dd.nwg = dd.tiles_m * dd.tiles_n * d.splits;
-  hipLaunchKernelGGL(kern, dim3(dd.nwg), dim3(768), lds, st, dd);
+  hipLaunchKernelGGL(kern, dim3(dd.nwg), dim3(64 * (WM * WN + NL)), lds, st, dd);
   return aldm_launch_status("igemm_ws");
+}
+
+template <int BM, int BN, int WM, int WN, int NL, int S>
+int launch_ws_epi(const IgemmDev& d, hipStream_t st) {
+  const bool lean = d.splits <= 1 && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE;
+  if (d.splits > 1) return launch_ws<BM, BN, WM, WN, NL, S, 3>(d, st);
+  if (lean && d.qstat) return launch_ws<BM, BN, WM, WN, NL, S, 4>(d, st);
+  if (lean) return launch_ws<BM, BN, WM, WN, NL, S, 1>(d, st);
+  return launch_ws<BM, BN, WM, WN, NL, S, 0>(d, st);
+}
+
+static int ws_refuse(const IgemmDev& d, int Rp, bool vt) {
+  const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u && d.x2_bytes < 0x80000000u;
+  if (!fast || Rp != 0 || vt || d.ln_s || d.geglu) {
+    aldm_set_error("igemm: the wave-specialised tiles take plain launches only (LDS-DMA path, no LoRA / V^T / folded LayerNorm / GEGLU)");
+    return ALDM_E_UNSUPPORTED;
+  }
+  return ALDM_OK;
 }
 
 }  // namespace aldm_igemm_detail
 
 int aldm_launch_tile_256x128ws(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   using namespace aldm_igemm_detail;
-  const bool fast = d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.x_bytes < 0x80000000u && d.x2_bytes < 0x80000000u;
-  if (!fast || Rp != 0 || vt || d.ln_s || d.x3 || d.geglu) {
-    aldm_set_error("igemm: the wave-specialised tile takes plain launches only (LDS-DMA path, no LoRA / V^T / folded LayerNorm / fused 1x1 segment / GEGLU)");
-    return ALDM_E_UNSUPPORTED;
-  }
-  const bool lean = d.splits <= 1 && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE;
-  if (d.splits > 1) return launch_ws<3, 3>(d, st);
-  if (lean && d.qstat) return launch_ws<3, 4>(d, st);
-  if (lean) return launch_ws<3, 1>(d, st);
-  return launch_ws<3, 0>(d, st);
+  if (int rc = ws_refuse(d, Rp, vt)) return rc;
+  return launch_ws_epi<256, 128, 4, 2, 4, 3>(d, st);
+}
+// 4 compute waves + 4 loader waves on the small tiles; ring 3 or 4 (24 KB per stage)
+int aldm_launch_tile_64x128ws(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
+  using namespace aldm_igemm_detail;
+  if (int rc = ws_refuse(d, Rp, vt)) return rc;
+  if (ring == 4) return launch_ws_epi<64, 128, 2, 2, 4, 4>(d, st);
+  return launch_ws_epi<64, 128, 2, 2, 4, 3>(d, st);
+}
+int aldm_launch_tile_128x64ws(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
+  using namespace aldm_igemm_detail;
+  if (int rc = ws_refuse(d, Rp, vt)) return rc;
+  if (ring == 4) return launch_ws_epi<128, 64, 2, 2, 4, 4>(d, st);
+  return launch_ws_epi<128, 64, 2, 2, 4, 3>(d, st);
 }

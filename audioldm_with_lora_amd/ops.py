@@ -203,7 +203,7 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     return max(2, min(want, fit))
 
 
-TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64), 12: (256, 128)}
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64), 12: (256, 128), 13: (64, 128), 14: (128, 64)}
 HALO_ROWS = {7: 320, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip; 128x128: three or five DMA passes)
 
 
@@ -272,7 +272,8 @@ class Tuner:
         for t in [2, 3, 1, 4] + ([6] if (fast_path and not has_vt and ktiles >= 8) else []) + (
                 [9, 12] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M >= 32768 and pw.N % 128 == 0 and pw.ln_s is None
                             and not pw.geglu and not pw.Cext) else []) + (
-                [10, 11] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M <= 8192) else []):
+                [10, 11] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M <= 8192) else []) + (
+                [13, 14] if (fast_path and not has_vt and not pw.Rp and ktiles >= 8 and M <= 8192 and pw.ln_s is None and not pw.geglu) else []):
             bm, bn = TILE_DIMS[t]
             if has_vt and a.vt_col0 % bn:
                 continue
@@ -282,7 +283,7 @@ class Tuner:
                 sp_list += [sp for sp in (2, 3, 4, 6, 8, 12, 16)
                             if sp <= ktiles // 2 and base * sp <= 2560 and sp * M * pw.N * 4 <= (1 << 28)]
             for sp in sp_list:
-                for rg in ((3,) if t == 12 else (2, 3) if t in (6, 9) else (2, 3, 4)):
+                for rg in ((3,) if t == 12 else (3, 4) if t in (13, 14) else (2, 3) if t in (6, 9) else (2, 3, 4)):
                     cands.append((t, rg, sp))
         if forced_splits in (None, 1):
             cands += [(t, rg, 1) for t in halo for rg in (2, 3, 4)]
@@ -342,13 +343,14 @@ def save_tuned(path=TUNED_PATH):
                    "igemm": {k: list(v) for k, v in sorted(TUNED.items())}}, f, indent=0)
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8", 12: "256x128ws"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8", 12: "256x128ws", 13: "64x128ws", 14: "128x64ws"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event, site) per C-ABI call.
 # Events are recorded on the stream the kernel is launched on.  SITE tags the launches of one fused-LoRA attention module
 # (unet.run_attention) so that bench.py can price the module as a whole.
 PROFILE = None
 SITE = None
+KEYLOG = None        # with PROFILE: (row index, (tuning-table key, (tile, ring, splits) used)) of every igemm launch (tools/ab_overlay.py)
 
 
 def _launch(label, flops, nbytes, fn):
@@ -589,6 +591,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         gn_defer = ct % ng == 0 and cg % 4 == 0 and pw.N % cg == 0 and OH * OW * (cg // 4) <= 4096
     fast_path = not (pw.Cin % 64 or (x2 is not None and x2.shape[3] % 64) or in_act)
     tuning = False
+    key = None
     if tile == 0 and ring == 0:
         # launch configuration: the measured table (tuned_gfx950.json, written by tools/autotune.py) where it has this
         # GEMM, else the heuristics below.  A caller-fixed split count stays fixed (it is part of the key).
@@ -698,6 +701,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         e1.record()
         TUNER.record(key, (tile, ring, splits), e0, e1)
         return y if gn_defer else finish()
+    if KEYLOG is not None and PROFILE is not None:
+        KEYLOG.append((len(PROFILE), (key, (tile, ring, splits))))
     check(_launch(label, flops, nbytes, lambda: lib.aldm_igemm(C.byref(a), _stream())), "aldm_igemm")
     return finish()
 

@@ -140,6 +140,8 @@ enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE
        ALDM_TILE_256x128_W8 = 9 /* 8-wave workgroup, 64x64 per wave: big-M plain convolutions (VAE, vocoder) */,
        ALDM_TILE_256x128_WS = 12 /* wave-specialised: 8 compute waves + 4 loader waves that only feed the LDS-DMA ring (csrc/igemm_ws.hip);
           plain big-M convolutions: LDS-DMA path, no LoRA / V^T / folded LayerNorm / fused 1x1 segment / GEGLU */,
+       ALDM_TILE_64x128_WS = 13, ALDM_TILE_128x64_WS = 14 /* the same split on the small tiles: 4 compute + 4 loader waves (the split-K
+          convolutions of the UNet's low-resolution levels; also with the fused 1x1 second-source segment) */,
        ALDM_TILE_64x128_W8 = 10, ALDM_TILE_128x64_W8 = 11 /* 8-wave forms of the small tiles: two waves per SIMD where the grid is ~one
           workgroup per CU (split-K convolutions of the low-resolution levels); LDS-DMA path, no LoRA / V^T */ };
 

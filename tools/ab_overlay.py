@@ -1,0 +1,89 @@
+"""In-step A/B of launch configurations for a family of igemm keys (config 2 denoise step, replayed graph, kineto durations).
+
+The isolated tuner (tools/autotune.py) ranks a configuration by one launch behind a sleep kernel; inside the step the neighbours'
+L2 / Infinity-Cache footprint and the tail of the previous launch change the ranking (round 4: the re-tuned table was 3 % slower
+in the step than the old one).  This tool therefore measures IN the step: every variant re-captures the step's graph with a rule
+applied to all eligible keys, the per-launch durations are joined by launch index, and the best variant per KEY (summed over its
+launches) goes to an overlay JSON that ALDM_TUNED_PATCH or a merge into tuned_gfx950.json can adopt.
+
+usage: python tools/ab_overlay.py out.json [small|big]"""
+import json, os, re, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from audioldm_with_lora_amd import ops
+from audioldm_with_lora_amd.engine import DenoiseEngine
+from audioldm_with_lora_amd.scheduler import DDIMScheduler
+
+out_path = sys.argv[1]
+family = sys.argv[2] if len(sys.argv) > 2 else "small"
+B = 4
+unet, _ = bench.build_unet(4)
+lat, pe, ne = bench.synth_inputs(B, 250, 16)
+BASE = dict(ops.TUNED)
+USED = {}
+
+
+def eligible(key):
+    m = re.match(r"M(\d+) N(\d+) ", key)
+    if not m or " k3x3 s1 " not in key or " f1" not in key or " gi" in key or " r0 " not in key:
+        return False
+    M = int(m.group(1))
+    return (256 <= M <= 8192) if family == "small" else M > 8192
+
+
+def measure(overlay):
+    ops.TUNED.clear(); ops.TUNED.update(BASE); ops.TUNED.update(overlay)
+    eng = DenoiseEngine(unet, DDIMScheduler(), B, 250, 16, 200, 2.5)
+    eng.set_condition(pe, ne); eng.set_latents(lat)
+    eng.capture()
+    for _ in range(5):
+        eng.step()
+    ops.KEYLOG = []
+    rows = bench.launch_rows(eng)
+    keylog, ops.KEYLOG = dict(ops.KEYLOG), None
+    kern, span = bench.trace_replays(eng)
+    j = bench.join_trace(rows, kern)
+    per_key = {}
+    for i, r in enumerate(j):
+        k, cfg = keylog.get(i, (None, None))
+        if k is not None:
+            us = r[5]
+            if " gn" in k and i + 1 < len(j) and j[i + 1][0].startswith("groupnorm"):
+                us += j[i + 1][5]                           # a deferred split-K reduce is paid by the GroupNorm that follows
+            per_key[k] = per_key.get(k, 0.0) + us
+            USED[k] = cfg
+    return per_key, sum(r[5] for r in j), span
+
+
+base_keys, base_tot, base_span = measure({})
+keys = [k for k in base_keys if eligible(k)]
+print(f"base: kernel time {base_tot:.1f} us, span {base_span:.1f} us; {len(keys)} eligible keys", flush=True)
+variants = {"base": (base_keys, {})}
+base_used = dict(USED)
+rules = [("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1), ("128x64ws r4", 14, 4, 1), ("64x128ws r3 /2", 13, 3, 2), ("128x64ws r3 /2", 14, 3, 2),
+         ("128x64ws r4 /2", 14, 4, 2)] if family == "small" else [("256x128ws", 12, 3, 1)]
+for name, tile, ring, spdiv in rules:
+    ov = {}
+    for k in keys:
+        sp = base_used[k][2]
+        if spdiv > 1 and sp < 2 * spdiv:
+            continue
+        ov[k] = (tile, ring, max(1, sp // spdiv))
+    try:
+        pk, tot, span = measure(ov)
+    except Exception as e:                                  # a key the tile refuses: drop the variant, say why
+        print(f"{name}: {str(e)[:160]}", flush=True)
+        continue
+    variants[name] = (pk, ov)
+    print(f"{name}: kernel time {tot:.1f} us, span {span:.1f} us", flush=True)
+patch = {}
+for k in keys:
+    best = min((v for v in variants if v == "base" or k in variants[v][1]), key=lambda v: variants[v][0].get(k, 1e9))
+    line = "  ".join(f"{v} {variants[v][0].get(k, float('nan')) if (v == 'base' or k in variants[v][1]) else float('nan'):7.2f}" for v in variants)
+    print(f"{k:100s} {line}  -> {best}")
+    if best != "base" and variants[best][0][k] < 0.985 * base_keys[k]:
+        patch[k] = list(variants[best][1][k])
+pk, tot, span = measure({k: tuple(v) for k, v in patch.items()})
+print(f"merged overlay ({len(patch)} keys): kernel time {tot:.1f} us (base {base_tot:.1f}), span {span:.1f} us (base {base_span:.1f})")
+with open(out_path, "w") as f:
+    json.dump(patch, f, indent=0)
