@@ -6,7 +6,8 @@ in the step than the old one).  This tool therefore measures IN the step: every 
 applied to all eligible keys, the per-launch durations are joined by launch index, and the best variant per KEY (summed over its
 launches) goes to an overlay JSON that ALDM_TUNED_PATCH or a merge into tuned_gfx950.json can adopt.
 
-usage: python tools/ab_overlay.py out.json [small|big]"""
+usage: python tools/ab_overlay.py out.json [small|big|all] [infer|train]     (train: config 3's LoRA step, batch 8, rank 8; per-key times
+from hipEvent pairs of an eager step queued behind a sleep kernel, totals from the replayed graph)"""
 import json, os, re, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -16,6 +17,7 @@ from audioldm_with_lora_amd.scheduler import DDIMScheduler
 
 out_path = sys.argv[1]
 family = sys.argv[2] if len(sys.argv) > 2 else "small"
+workload = sys.argv[3] if len(sys.argv) > 3 else "infer"
 B = 4
 unet, _ = bench.build_unet(4)
 lat, pe, ne = bench.synth_inputs(B, 250, 16)
@@ -23,12 +25,51 @@ BASE = dict(ops.TUNED)
 USED = {}
 
 
+def key_m(key):
+    return int(re.match(r"M(\d+) ", key).group(1))
+
+
 def eligible(key):
-    m = re.match(r"M(\d+) N(\d+) ", key)
-    if not m or " k3x3 s1 " not in key or " f1" not in key or " gi" in key or " r0 " not in key:
+    if not re.match(r"M(\d+) N(\d+) ", key) or any(t not in key for t in (" f1", " r0 ", " vt0 ", " g0 ", " ln0 ")):
         return False
-    M = int(m.group(1))
-    return (256 <= M <= 8192) if family == "small" else M > 8192
+    if any(t in key for t in (" gi", " lp", " rs", " vd")) or (family != "all" and " k3x3 s1 " not in key):
+        return False
+    M = key_m(key)
+    return (256 <= M <= 8192) if family == "small" else M > 8192 if family == "big" else M >= 256
+
+
+def measure_train(overlay, total=False):
+    from audioldm_with_lora_amd.training import LoraTrainer
+    ops.TUNED.clear(); ops.TUNED.update(BASE); ops.TUNED.update(overlay)
+    g = torch.Generator().manual_seed(0)
+    lat, noise = torch.randn(8, 8, 256, 16, generator=g).cuda(), torch.randn(8, 8, 256, 16, generator=g).cuda()
+    t = torch.randint(0, 1000, (8,), generator=g).cuda()
+    emb = torch.nn.functional.normalize(torch.randn(8, 512, generator=g), dim=-1).cuda()
+    tr = LoraTrainer(unet, DDIMScheduler(), lr=1e-5, weight_decay=1e-5, max_train_steps=97000, use_graph=False)
+    for _ in range(2):
+        tr.step(lat, noise, t, emb)
+    torch.cuda.synchronize()
+    ops.PROFILE, ops.KEYLOG = [], []
+    ops.sleep_us(100000)
+    tr.step(lat, noise, t, emb)
+    torch.cuda.synchronize()
+    rows, keylog, ops.PROFILE, ops.KEYLOG = ops.PROFILE, dict(ops.KEYLOG), None, None
+    per_key = {}
+    for i, r in enumerate(rows):
+        k, cfg = keylog.get(i, (None, None))
+        if k is not None:
+            per_key[k] = per_key.get(k, 0.0) + r[3].elapsed_time(r[4]) * 1e3
+            USED[k] = cfg
+    tot = span = float("nan")
+    if total:
+        trg = LoraTrainer(unet, DDIMScheduler(), lr=1e-5, weight_decay=1e-5, max_train_steps=97000)
+        for _ in range(5):
+            trg.step(lat, noise, t, emb)
+        torch.cuda.synchronize()
+        per, span, kept = bench.trace_steps(lambda: trg.step(lat, noise, t, emb), "adamw_flat", reps=6)
+        tot = sum(us for _, us in per)
+    return per_key, tot, span
+
 
 
 def measure(overlay):
@@ -55,18 +96,25 @@ def measure(overlay):
     return per_key, sum(r[5] for r in j), span
 
 
-base_keys, base_tot, base_span = measure({})
+if workload == "train":
+    unet, _ = bench.build_unet(8)
+    infer_measure, measure = measure, (lambda ov, total=False: measure_train(ov, total))
+    base_keys, base_tot, base_span = measure({}, total=True)
+else:
+    base_keys, base_tot, base_span = measure({})
 keys = [k for k in base_keys if eligible(k)]
 print(f"base: kernel time {base_tot:.1f} us, span {base_span:.1f} us; {len(keys)} eligible keys", flush=True)
 variants = {"base": (base_keys, {})}
 base_used = dict(USED)
-rules = [("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1), ("128x64ws r4", 14, 4, 1), ("64x128ws r3 /2", 13, 3, 2), ("128x64ws r3 /2", 14, 3, 2),
-         ("128x64ws r4 /2", 14, 4, 2)] if family == "small" else [("256x128ws", 12, 3, 1)]
+SMALL = [("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1), ("128x64ws r4", 14, 4, 1), ("64x128ws r3 /2", 13, 3, 2), ("128x64ws r3 /2", 14, 3, 2),
+         ("128x64ws r4 /2", 14, 4, 2)]
+BIG = [("256x128ws", 12, 3, 1), ("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1)]
+rules = SMALL if family == "small" else BIG if family == "big" else SMALL + [("256x128ws", 12, 3, 1)]
 for name, tile, ring, spdiv in rules:
     ov = {}
     for k in keys:
         sp = base_used[k][2]
-        if spdiv > 1 and sp < 2 * spdiv:
+        if (spdiv > 1 and sp < 2 * spdiv) or (tile == 12 and key_m(k) <= 8192):
             continue
         ov[k] = (tile, ring, max(1, sp // spdiv))
     try:
@@ -83,7 +131,7 @@ for k in keys:
     print(f"{k:100s} {line}  -> {best}")
     if best != "base" and variants[best][0][k] < 0.985 * base_keys[k]:
         patch[k] = list(variants[best][1][k])
-pk, tot, span = measure({k: tuple(v) for k, v in patch.items()})
+pk, tot, span = measure({k: tuple(v) for k, v in patch.items()}, True) if workload == "train" else measure({k: tuple(v) for k, v in patch.items()})
 print(f"merged overlay ({len(patch)} keys): kernel time {tot:.1f} us (base {base_tot:.1f}), span {span:.1f} us (base {base_span:.1f})")
 with open(out_path, "w") as f:
     json.dump(patch, f, indent=0)
