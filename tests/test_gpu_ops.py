@@ -631,6 +631,40 @@ def test_conv3x3_eight_wave_small_tiles(ops, tile, splits, ring):
     close(to_nchw(y), want)
 
 
+@pytest.mark.parametrize("tile,ring", [(13, 3), (13, 4), (14, 3), (14, 4)])
+@pytest.mark.parametrize("kind", ["splitk_res", "plain_ragged", "shortcut_two_src", "shortcut_splitk", "one_by_one"])
+def test_conv_wave_specialised_small_tiles(ops, tile, ring, kind):
+    """tiles 13 / 14 (csrc/igemm_ws.hip on 64x128 / 128x64: 4 compute + 4 loader waves) == torch for the launch forms of the UNet's
+    low-resolution levels: split-K with residual, ragged M and N, conv2 + conv_shortcut as one GEMM (the fused 1x1 segment over one or
+    two block inputs, whole or split-K with the split boundary inside / at the segment), 1x1 over two sources."""
+    g = torch.Generator().manual_seed(130 + tile)
+    if kind == "splitk_res":
+        x = bf(torch.randn(8, 320, 32, 2, generator=g))
+        w, b = bf(torch.randn(320, 320, 3, 3, generator=g) * 0.03), torch.randn(320, generator=g)
+        r = bf(torch.randn(8, 320, 32, 2, generator=g))
+        y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), pad=(1, 1), res=nhwc(r), tile=tile, ring=ring, splits=6)
+        close(to_nchw(y), F.conv2d(x, w, b, padding=1) + r)
+    elif kind == "plain_ragged":
+        x = bf(torch.randn(3, 128, 63, 4, generator=g))                   # M = 756: not a multiple of either tile height
+        w, b = bf(torch.randn(200, 128, 3, 3, generator=g) * 0.04), torch.randn(200, generator=g)
+        close(to_nchw(ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), pad=(1, 1), tile=tile, ring=ring)), F.conv2d(x, w, b, padding=1))
+    elif kind in ("shortcut_two_src", "shortcut_splitk"):
+        h = bf(torch.randn(8, 128, 32, 2, generator=g))
+        xa, xb = bf(torch.randn(8, 128, 32, 2, generator=g)), bf(torch.randn(8, 64, 32, 2, generator=g))
+        w, b = bf(torch.randn(128, 128, 3, 3, generator=g) * 0.04), torch.randn(128, generator=g)
+        ws_, bs_ = bf(torch.randn(128, 192, 1, 1, generator=g) * 0.06), torch.randn(128, generator=g)
+        want = F.conv2d(h, w, b, padding=1) + F.conv2d(torch.cat([xa, xb], 1), ws_, bs_)
+        pw = ops.pack_conv_shortcut(w.to(DEV), b.to(DEV), ws_.to(DEV), bs_.to(DEV))
+        for sp in ((1,) if kind == "shortcut_two_src" else (3, 7, 21)):    # 18 + 3 K-tiles: boundaries inside the taps, at and inside the segment
+            y = ops.conv(nhwc(h), pw, pad=(1, 1), x3=nhwc(xa), x4=nhwc(xb), tile=tile, ring=ring, splits=sp)
+            close(to_nchw(y), want)
+    else:
+        x, x2 = bf(torch.randn(8, 256, 63, 4, generator=g)), bf(torch.randn(8, 128, 63, 4, generator=g))
+        w, b = bf(torch.randn(256, 384, 1, 1, generator=g) * 0.05), torch.randn(256, generator=g)
+        y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), x2=nhwc(x2), tile=tile, ring=ring)
+        close(to_nchw(y), F.conv2d(torch.cat([x, x2], 1), w, b))
+
+
 @pytest.mark.parametrize("kind", ["plain", "two_src_res", "upsample", "splitk", "act_out2", "conv1d_dil"])
 def test_conv_wave_specialised_tile(ops, kind):
     """tile 12 (csrc/igemm_ws.hip): 8 compute waves + 4 loader waves feeding the LDS-DMA ring -- same results as torch for every launch
