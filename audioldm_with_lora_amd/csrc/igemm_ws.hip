@@ -23,7 +23,15 @@ namespace aldm_igemm_detail {
 // wave per SIMD nor a stagger hid one behind the other -- because every wave still had to issue its share of the DMA.
 // With 4 compute waves + NL loader waves the K-tile costs max(DMA, MFMA): instantiated as 64x128 and 128x64 (+ the fused 1x1
 // second-source segment those levels' conv2 launches carry).
-template <int BM, int BN, int WM, int WN, int NL, int S, int EPI>
+//
+// RS (register-staged loaders, ring = 2): the loader waves fetch with plain buffer_load_dwordx4 into VGPRs and ds_write_b128 the tile
+// into the SAME LDS image one barrier later, instead of `buffer_load ... lds` (two tiles in flight in 2 L x 4 VGPRs, two LDS stages).
+// An experiment, kept as a selectable form: attn_block64.hip's weight stream runs twice as fast this way, here it does NOT pay --
+// 15 - 25 % slower than the LDS-DMA loaders on every shape tried (M 512 N 640 K 5760: 18.5 against 15.8 us; M 8000 N 256 K 2304: 26.1
+// against 20.5; M 32000 N 256 K 2304 on 256x128: 54.2 against 43.1; profiles/r04_ws_register_staged_loaders.log): the return trip
+// load -> ds_write -> lgkmcnt(0) must fit between two barriers, and the compiler's waits keep ~one tile in flight at issue time.
+typedef unsigned int ws_u32x4 __attribute__((ext_vector_type(4)));
+template <int BM, int BN, int WM, int WN, int NL, int S, int EPI, bool RS = false>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(IgemmDev)>();
@@ -37,6 +45,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const Ige
   constexpr int STAGE = (BM + BN) * 128;
   constexpr unsigned OOB = 0x80000000u;
   static_assert((D - 1) * L < 64, "vmcnt immediate");
+  static_assert(!RS || S == 2, "register staging: two LDS stages (the loader's registers are the third)");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [S][ A: BM x 128 B | B: BN x 128 B ]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const Ige
     int a_soff = 0, b_soff = kt0 * BK * 2;
     const int IHv = p.UH > 0 ? p.UH : p.IH, IWv = p.UW > 0 ? p.UW : p.IW;
 
-    auto issue = [&](int kt, int stage) {
+    auto issue = [&](int kt, int stage, ws_u32x4* R) {      // R (RS only): the L registers that receive the tile instead of LDS
       char* sbase = smem + stage * STAGE + lwave * 1024;   // + pass * RPP * 128: this wave's 8 rows of the pass
       const bool live = kt < kt1;
       const bool ext = s_kh >= p.KH;                    // (scalar) inside the fused 1x1 segment
@@ -129,23 +138,23 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const Ige
         a_soff = (s_c0 - (src2 ? cA : 0)) * 2;
         b_soff = kt * BK * 2;
       }
+      auto fetch = [&](const __amdgpu_buffer_rsrc_t rs, int i, char* dst, unsigned voff, int soff) {
+        if constexpr (RS) R[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+      };
       if (ext) {   // descriptors built on the spot (transient SGPRs), as in igemm_pipe_kernel
         const __amdgpu_buffer_rsrc_t rs_e = src2 ? make_rsrc(p.x4, p.x4_bytes) : make_rsrc(p.x3, p.x3_bytes);
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, live ? cur_off[ps] : OOB, a_soff, 0, 0);
+        for (int ps = 0; ps < A_PASSES; ++ps) fetch(rs_e, ps, sbase + ps * (RPP * 128), live ? cur_off[ps] : OOB, a_soff);
       } else if (src2) {
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, live ? cur_off[ps] : OOB, a_soff, 0, 0);
+        for (int ps = 0; ps < A_PASSES; ++ps) fetch(rs_x2, ps, sbase + ps * (RPP * 128), live ? cur_off[ps] : OOB, a_soff);
       } else {
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + ps * (RPP * 128)), 16, live ? cur_off[ps] : OOB, a_soff, 0, 0);
+        for (int ps = 0; ps < A_PASSES; ++ps) fetch(rs_x, ps, sbase + ps * (RPP * 128), live ? cur_off[ps] : OOB, a_soff);
       }
 #pragma unroll
-      for (int ps = 0; ps < W_PASSES; ++ps)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * 128 + ps * (RPP * 128)), 16, live ? b_off[ps] : OOB, b_soff, 0, 0);
+      for (int ps = 0; ps < W_PASSES; ++ps) fetch(rs_w, A_PASSES + ps, sbase + BM * 128 + ps * (RPP * 128), live ? b_off[ps] : OOB, b_soff);
       if (live) {   // advance the scalar cursor by one K-tile
         s_c0 += BK;
         if (s_c0 == cA && (ext ? k_cin4 : k_cin2) > 0) s_fresh = true;
@@ -156,13 +165,44 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const Ige
         }
       }
     };
+    if constexpr (RS) {
+      // tile t: fetched into R[t & 1] two iterations ahead, written to LDS stage t & 1 one iteration ahead (after the barrier that says
+      // every compute wave is done with tile t - 2, the stage's previous tenant), visible to the compute waves at barrier t.
+      ws_u32x4 R0[L], R1[L];
+      auto put = [&](int stage, const ws_u32x4* R) {
+        char* sbase = smem + stage * STAGE + lwave * 1024;
 #pragma unroll
-    for (int s = 0; s < D; ++s) issue(kt0 + s, s);
+        for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<ws_u32x4*>(sbase + ps * (RPP * 128) + lane * 16) = R[ps];
+#pragma unroll
+        for (int ps = 0; ps < W_PASSES; ++ps) *reinterpret_cast<ws_u32x4*>(sbase + BM * 128 + ps * (RPP * 128) + lane * 16) = R[A_PASSES + ps];
+      };
+      issue(kt0, 0, R0);
+      issue(kt0 + 1, 1, R1);
+      put(0, R0);
+      issue(kt0 + 2, 0, R0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): tile kt0 is written
+      for (int kt = kt0; kt < kt1; kt += 2) {
+        __builtin_amdgcn_s_barrier();                   // tile kt handed over; tile kt - 1's stage (1) is free
+        put(1, R1);
+        issue(kt + 3, 1, R1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (kt + 1 >= kt1) break;
+        __builtin_amdgcn_s_barrier();                   // tile kt + 1 handed over; stage 0 is free
+        put(0, R0);
+        issue(kt + 4, 0, R0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0): the dummy fetches past the end
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(kt0 + s, s, nullptr);
     int st_fill = D;
     for (int kt = kt0; kt < kt1; ++kt) {
       wait_vmcnt<(D - 1) * L>();                        // tile kt (this wave's rows of it) has landed
       __builtin_amdgcn_s_barrier();                     // ... and every compute wave is done with tile kt - 1
-      issue(kt + D, st_fill);                           // refill that stage while the compute waves multiply tile kt
+      issue(kt + D, st_fill, nullptr);                  // refill that stage while the compute waves multiply tile kt
       st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
     }
     wait_vmcnt<0>();                                    // the dummy tiles past the end too: the epilogue re-uses the ring's LDS
@@ -210,13 +250,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void igemm_ws_kernel(const Ige
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NL, int S, int EPI>
+template <int BM, int BN, int WM, int WN, int NL, int S, int EPI, bool RS = false>
 int launch_ws(const IgemmDev& d, hipStream_t st) {
   constexpr size_t ring = (size_t)S * (BM + BN) * 128;
   constexpr size_t lds = (ring > (size_t)EpiCfg<BM, BN>::BYTES ? ring : (size_t)EpiCfg<BM, BN>::BYTES) + 2 * BM * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static unsigned long long attr_done = 0;
-  auto kern = igemm_ws_kernel<BM, BN, WM, WN, NL, S, EPI>;
+  auto kern = igemm_ws_kernel<BM, BN, WM, WN, NL, S, EPI, RS>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_ws")) return rc;
   if ((d.qstat || d.rowstat) && d.N % BN != 0) {
     aldm_set_error("igemm: qstat_out / rowstat_out need Cout %d to be a multiple of the tile width %d", d.N, BN);
@@ -233,13 +273,13 @@ int launch_ws(const IgemmDev& d, hipStream_t st) {
   return aldm_launch_status("igemm_ws");
 }
 
-template <int BM, int BN, int WM, int WN, int NL, int S>
+template <int BM, int BN, int WM, int WN, int NL, int S, bool RS = false>
 int launch_ws_epi(const IgemmDev& d, hipStream_t st) {
   const bool lean = d.splits <= 1 && d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE;
-  if (d.splits > 1) return launch_ws<BM, BN, WM, WN, NL, S, 3>(d, st);
-  if (lean && d.qstat) return launch_ws<BM, BN, WM, WN, NL, S, 4>(d, st);
-  if (lean) return launch_ws<BM, BN, WM, WN, NL, S, 1>(d, st);
-  return launch_ws<BM, BN, WM, WN, NL, S, 0>(d, st);
+  if (d.splits > 1) return launch_ws<BM, BN, WM, WN, NL, S, 3, RS>(d, st);
+  if (lean && d.qstat) return launch_ws<BM, BN, WM, WN, NL, S, 4, RS>(d, st);
+  if (lean) return launch_ws<BM, BN, WM, WN, NL, S, 1, RS>(d, st);
+  return launch_ws<BM, BN, WM, WN, NL, S, 0, RS>(d, st);
 }
 
 static int ws_refuse(const IgemmDev& d, int Rp, bool vt) {
@@ -256,18 +296,21 @@ static int ws_refuse(const IgemmDev& d, int Rp, bool vt) {
 int aldm_launch_tile_256x128ws(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   using namespace aldm_igemm_detail;
   if (int rc = ws_refuse(d, Rp, vt)) return rc;
+  if (ring == 2) return launch_ws_epi<256, 128, 4, 2, 4, 2, true>(d, st);     // ring 2 = register-staged loaders
   return launch_ws_epi<256, 128, 4, 2, 4, 3>(d, st);
 }
 // 4 compute waves + 4 loader waves on the small tiles; ring 3 or 4 (24 KB per stage)
 int aldm_launch_tile_64x128ws(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   using namespace aldm_igemm_detail;
   if (int rc = ws_refuse(d, Rp, vt)) return rc;
+  if (ring == 2) return launch_ws_epi<64, 128, 2, 2, 4, 2, true>(d, st);
   if (ring == 4) return launch_ws_epi<64, 128, 2, 2, 4, 4>(d, st);
   return launch_ws_epi<64, 128, 2, 2, 4, 3>(d, st);
 }
 int aldm_launch_tile_128x64ws(const aldm_igemm_detail::IgemmDev& d, int Rp, bool vt, int ring, hipStream_t st) {
   using namespace aldm_igemm_detail;
   if (int rc = ws_refuse(d, Rp, vt)) return rc;
+  if (ring == 2) return launch_ws_epi<128, 64, 2, 2, 4, 2, true>(d, st);
   if (ring == 4) return launch_ws_epi<128, 64, 2, 2, 4, 4>(d, st);
   return launch_ws_epi<128, 64, 2, 2, 4, 3>(d, st);
 }

@@ -631,7 +631,7 @@ def test_conv3x3_eight_wave_small_tiles(ops, tile, splits, ring):
     close(to_nchw(y), want)
 
 
-@pytest.mark.parametrize("tile,ring", [(13, 3), (13, 4), (14, 3), (14, 4)])
+@pytest.mark.parametrize("tile,ring", [(13, 3), (13, 4), (14, 3), (14, 4), (13, 2), (14, 2)])   # ring 2 = register-staged loaders
 @pytest.mark.parametrize("kind", ["splitk_res", "plain_ragged", "shortcut_two_src", "shortcut_splitk", "one_by_one"])
 def test_conv_wave_specialised_small_tiles(ops, tile, ring, kind):
     """tiles 13 / 14 (csrc/igemm_ws.hip on 64x128 / 128x64: 4 compute + 4 loader waves) == torch for the launch forms of the UNet's

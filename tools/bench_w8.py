@@ -30,6 +30,15 @@ def run(name, B, H, W, Cin, Cout, cfgs, nrot=8):
             best = min(best, e0.elapsed_time(e1) / (3 * nrot))
         print(f"{name} tile {ops.TILE_NAMES[tile]:10s} ring {ring} splits {sp:2d}: {best * 1e3:7.2f} us (conv + reduce){'' if same else '  MISMATCH'}", flush=True)
 
+if len(sys.argv) > 1 and sys.argv[1] == "rs":   # register-staged loaders (ring 2) against LDS-DMA loaders (ring 3)
+    run("M512 N640 K5760", 8, 32, 2, 640, 640, [(11, 3, 6), (14, 3, 6), (14, 4, 6), (14, 2, 6), (13, 3, 6), (13, 2, 6), (14, 2, 4), (14, 2, 3)])
+    run("M512 N1280 K11520", 8, 32, 2, 1280, 1280, [(14, 4, 3), (14, 2, 3), (14, 2, 6), (13, 2, 3)])
+    run("M2016 N384 K3456", 8, 63, 4, 384, 384, [(13, 3, 4), (13, 2, 4), (14, 2, 4), (13, 2, 3), (13, 2, 2)])
+    run("M2016 N384 K9216(C1024)", 8, 63, 4, 1024, 384, [(3, 3, 8), (13, 3, 4), (13, 2, 4), (14, 2, 4), (13, 2, 8)])
+    run("M8000 N256 K2304", 8, 125, 8, 256, 256, [(13, 3, 1), (13, 2, 1), (14, 2, 1), (13, 2, 2)])
+    run("M32000 N256 K2304", 8, 250, 16, 256, 256, [(12, 3, 1), (12, 2, 1), (9, 3, 1)])
+    run("M32000 N128 K1152", 8, 250, 16, 128, 128, [(12, 3, 1), (12, 2, 1), (7, 3, 1)])
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "ws":   # the wave-specialised small tiles (13: 64x128ws, 14: 128x64ws)
     run("M512 N640 K5760", 8, 32, 2, 640, 640, [(4, 3, 6), (11, 3, 6), (13, 3, 6), (13, 4, 6), (13, 4, 4), (13, 4, 8), (13, 4, 12), (14, 3, 6), (14, 4, 6), (14, 4, 12), (14, 4, 8)])
     run("M512 N1280 K11520", 8, 32, 2, 1280, 1280, [(4, 3, 6), (11, 3, 6), (13, 4, 6), (13, 4, 4), (13, 4, 3), (14, 4, 6), (14, 4, 4), (14, 4, 3)])
