@@ -36,6 +36,11 @@ extern "C" size_t aldm_igemm_workspace_bytes(const aldm_igemm_t* p) {
 extern "C" int aldm_igemm_effective_splits(const aldm_igemm_t* p) {
   if (!p || p->splits <= 1) return 1;
   const int nkt = cdiv(p->KH * p->KW * (p->Cin + p->Cin2), BK) + (p->x3 ? (p->Cin3 + (p->x4 ? p->Cin4 : 0)) / BK : 0);
+  if (p->tile == ALDM_TILE_HALO_128x128 || p->tile == ALDM_TILE_HALO_64x128 || p->tile == ALDM_TILE_HALO_128x128_WS ||
+      p->tile == ALDM_TILE_HALO_64x128_WS) {   // the halo tiles split by 64-channel chunk (9 taps each)
+    const int nch = (p->Cin + p->Cin2) / BK;
+    return cdiv(nch, cdiv(nch, p->splits > nch ? nch : p->splits));
+  }
   int splits = p->splits > nkt ? nkt : p->splits;
   const int per = cdiv(nkt, splits);
   return cdiv(nkt, per);
@@ -106,6 +111,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
   if (d.splits > d.nkt) d.splits = d.nkt;
   d.kt_per_split = cdiv(d.nkt, d.splits);
   d.splits = cdiv(d.nkt, d.kt_per_split);
+  d.ws_rows = d.M;
   d.tiles_n = 0; d.tiles_m = 0; d.nwg = 0;
   ALDM_CHECK_ARG(p->xcd_map >= 0 && p->xcd_map <= 2, "igemm: xcd_map must be 0 (auto), 1 (activation-stationary) or 2 (weight-stationary)");
   {
@@ -149,7 +155,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
 
   int tile = p->tile ? p->tile : pick_tile(d.M, d.N);
   if (p->gnin_gamma) {
-    ALDM_CHECK_ARG(tile == ALDM_TILE_HALO_128x128 || tile == ALDM_TILE_HALO_64x128, "igemm: gnin_* (GroupNorm of the input inside the launch) needs a halo tile");
+    ALDM_CHECK_ARG(tile == ALDM_TILE_HALO_128x128 || tile == ALDM_TILE_HALO_64x128 || tile == ALDM_TILE_HALO_128x128_WS || tile == ALDM_TILE_HALO_64x128_WS, "igemm: gnin_* (GroupNorm of the input inside the launch) needs a halo tile");
     const int Ct = p->Cin + p->Cin2;
     ALDM_CHECK_ARG(p->gnin_beta && p->gnin_q1 && (p->Cin2 == 0 || p->gnin_q2) && p->gnin_groups > 0 && p->gnin_groups <= 64 && Ct % p->gnin_groups == 0 &&
                    (Ct / p->gnin_groups) % 4 == 0 && Ct <= 512 && p->UH == 0 &&
@@ -174,8 +180,16 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_128x64_W8: rc = aldm_launch_tile_128x64w8(d, p->Rp, vt, p->ring, st); break;
     case ALDM_TILE_HALO_128x128:
     case ALDM_TILE_HALO_64x128:
+    case ALDM_TILE_HALO_128x128_WS:
+    case ALDM_TILE_HALO_64x128_WS:
       // (qstat_out is fine with the halo tiles: they are image-aligned, slot 0)
       if (p->Rp || vt || p->rowstat_out || p->x3) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics / second-source segment"); return ALDM_E_UNSUPPORTED; }
+      if (d.splits > 1) {   // split-K by whole 64-channel chunks: a chunk's halo serves its nine taps in one workgroup
+        const int nch = (d.Cin + d.Cin2) / BK;
+        const int cps = cdiv(nch, d.splits > nch ? nch : d.splits);
+        d.kt_per_split = 9 * cps;
+        d.splits = cdiv(nch, cps);
+      }
       rc = aldm_launch_halo(d, tile, p->ring, st);
       break;
     default: aldm_set_error("igemm: unknown tile %d", tile); return ALDM_E_UNSUPPORTED;

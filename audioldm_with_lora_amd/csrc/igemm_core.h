@@ -56,6 +56,7 @@ struct IgemmDev {
   int vt_col0, vt_ld; long long vt_bs; int vt_dual;
   int splits, kt_per_split, nkt;
   int tiles_n;
+  int ws_rows;                // rows of one split-K slab of the workspace (= the launch's M; the halo tiles cut p.M per image for the bound checks)
   int tiles_m, nwg, xmap;     // 1-D grid of tiles_m * tiles_n * splits workgroups; xmap: work item -> XCD order (see igemm_work_item)
   FastDiv fd_tiles_m, fd_splits;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
@@ -519,7 +520,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
       const int r = g / (BN / 8), c = (g - r * (BN / 8)) * 8;
       const int m = m0 + r, n = n0 + c;
       if (m >= p.M || n >= p.N) continue;
-      float* o = p.ws + ((long long)split * p.M + m) * p.N + n;
+      float* o = p.ws + ((long long)split * p.ws_rows + m) * p.N + n;
       const float* src = Cs + r * E::LD + c;
       if (n + 7 < p.N) {
         *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(src);

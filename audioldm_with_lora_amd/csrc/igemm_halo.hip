@@ -30,7 +30,11 @@ namespace aldm_igemm_detail {
 // wait it already does suffices -- before the barrier that releases it to the nine taps.  Padding pixels stay the zeros the DMA's
 // range check wrote (the convolution pads the ACTIVATION).  One 8 us groupnorm_apply launch and one write + read of the normalised
 // tensor disappear per ResnetBlock2D convolution at the 4000-pixel level.
-template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, int EPI /* 0 full, 1 lean, 4 lean + statistics */, bool GNIN = false>
+// Split-K (EPI 3, round 4): by whole 64-channel chunks -- a split owns chunks [split * cps, ..) with all nine taps, so its halo is
+// still fetched once; the fp32 partial tiles go to the workspace slabs like every other tile's (igemm_reduce_kernel or the deferred
+// GroupNorm sums them).  This is what lets the halo form fill the chip at the 1000- / 252- / 64-token levels, where an unsplit grid
+// is 20 - 130 workgroups: per output tile the texture path then carries 2.5x fewer bytes than the generic tiles' nine gathers.
+template <int BM, int BN, int WM, int WN, int HP /* halo DMA passes: HP * 64 rows */, int S, int EPI /* 0 full, 1 lean, 3 split-K partial, 4 lean + statistics */, bool GNIN = false>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(IgemmDev)>();
@@ -61,7 +65,12 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   const int HW2 = W + 2;
   const int rows_pt = BM / W;                           // image rows per tile (host guarantees BM % W == 0)
   const int tpi = (H + rows_pt - 1) / rows_pt;          // tiles per image
-  const int tile_m = fdiv(blockIdx.x, p.fd_tiles_n), tile_n = blockIdx.x - tile_m * p.tiles_n;
+  int wid = blockIdx.x, split = 0;
+  if constexpr (EPI == 3) {                             // (split slowest: the workgroups of one split share its weight columns)
+    split = fdiv(wid, p.fd_tiles_m);                    // fd_tiles_m: divisor = tiles per split (tiles_m * tiles_n), see launch_halo_v
+    wid -= split * p.tiles_m;
+  }
+  const int tile_m = fdiv(wid, p.fd_tiles_n), tile_n = wid - tile_m * p.tiles_n;
   const int img = tile_m / tpi, ty0 = (tile_m - img * tpi) * rows_pt;
   const int m0 = img * p.OHW + ty0 * W, n0 = tile_n * BN;
   const int halo_rows = (rows_pt + 2) * HW2;
@@ -95,9 +104,11 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   }
 
   const int nchunks = p.Ctot >> 6;
-  const int nitems = nchunks * 9;
+  const int c_begin = EPI == 3 ? split * (p.kt_per_split / 9) : 0;
+  const int c_end = EPI == 3 ? min(nchunks, c_begin + p.kt_per_split / 9) : nchunks;
+  const int nitems = (c_end - c_begin) * 9;
   // item cursor of the ISSUE side (scalar): chunk, tap
-  int i_c = 0, i_tap = 0;
+  int i_c = c_begin, i_tap = 0;
   auto issue = [&](int item, int stage) {
     const bool live = item < nitems;
     char* bdst = Bring + stage * BSTAGE + wave * 1024;
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   }
   {
     int st = 0, st_fill = D;
-    int c_c = 0, c_tap = 0, c_dy = 0, c_dx = 0;          // compute-side cursor
+    int c_c = c_begin, c_tap = 0, c_dy = 0, c_dx = 0;    // compute-side cursor
     for (int item = 0; item < nitems; ++item) {
       // item's data (and its halo, if it opens a chunk) must have landed; the D-1 younger items may still be in flight,
       // and they carry HP more DMA instructions when one of them opens a chunk
@@ -251,17 +262,249 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
   IgemmDev q = p;
   q.M = min(p.M, min(m0 + BM, (img + 1) * p.OHW));
   q.qtile = tile_m;                                         // GroupNorm hand-over table: one row per (image, tile in image), slot 0 only
-  igemm_epilogue<BM, BN, MI, NI, false, NT, EPI>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, 0, tid, nullptr);
+  igemm_epilogue<BM, BN, MI, NI, false, NT, EPI>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, nullptr);
 #endif
 }
 
+// Wave-specialised form (round 4): the eight compute waves of the halo tile plus FOUR loader waves that own the LDS-DMA ring -- the
+// halo of the next chunk and the nine weight tiles -- and, with GNIN, the in-place normalisation of every halo chunk (the thread that
+// DMA'd a piece normalises it once it has landed, before the barrier that releases the chunk).  Per tap the compute waves then go from
+// the barrier straight into the fragment reads and MFMAs: no DMA issue stall and no GroupNorm arithmetic on the waves that multiply
+// (igemm_ws.hip has the measurements behind the split).  Same LDS images, cursors, split-K rule and epilogue as igemm_halo_kernel.
 template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false>
+__global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  aldm_touch_kernargs<sizeof(IgemmDev)>();
+  static_assert(WM * WN == 8, "8 compute waves");
+  constexpr int NTC = 512, NTL = 256, RPP = NTL / 8;    // 32 rows per DMA pass of the four loader waves
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int HPL = HP * 64 / RPP;                    // halo DMA passes per loader thread per chunk
+  constexpr int W_PASSES = BN / RPP;
+  constexpr int D = S - 1;
+  constexpr int HALO_BYTES = HP * 64 * 128;
+  constexpr int BSTAGE = BN * 128;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert((D - 1) * W_PASSES + HPL < 64, "vmcnt immediate");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][halo: HP*64 x 128 B] [S][B: BN x 128 B] [GNIN tables]
+  char* const Hs = smem;
+  char* const Bring = smem + 2 * HALO_BYTES;
+  float* const gtab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + S * BSTAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NTC / 64;
+  const int W = p.OW, H = p.OH;
+  const int HW2 = W + 2;
+  const int rows_pt = BM / W;
+  const int tpi = (H + rows_pt - 1) / rows_pt;
+  int wid = blockIdx.x, split = 0;
+  if constexpr (EPI == 3) {
+    split = fdiv(wid, p.fd_tiles_m);
+    wid -= split * p.tiles_m;
+  }
+  const int tile_m = fdiv(wid, p.fd_tiles_n), tile_n = wid - tile_m * p.tiles_n;
+  const int img = tile_m / tpi, ty0 = (tile_m - img * tpi) * rows_pt;
+  const int m0 = img * p.OHW + ty0 * W, n0 = tile_n * BN;
+  const int halo_rows = (rows_pt + 2) * HW2;
+  const int nchunks = p.Ctot >> 6;
+  const int c_begin = EPI == 3 ? split * (p.kt_per_split / 9) : 0;
+  const int c_end = EPI == 3 ? min(nchunks, c_begin + p.kt_per_split / 9) : nchunks;
+  const int nitems = (c_end - c_begin) * 9;
+
+  if constexpr (GNIN) {
+    // per-channel (scale, shift) from the producers' statistics tables: the compute waves (idle until the first tile lands) do the
+    // arithmetic, every wave keeps the two barriers
+    float my_gamma = 0.f, my_beta = 0.f;
+    if (tid < p.Ctot) { my_gamma = p.gi_gamma[tid]; my_beta = p.gi_beta[tid]; }
+    const int groups = p.gi_groups, Cg = p.Ctot / groups;
+    if (tid < NTC) {
+      int lpg = 1;
+      while (lpg * 2 * groups <= NTC && lpg < 64) lpg *= 2;
+      const GnSrc s1{p.x, p.gi_q1, p.Cin, p.gi_bm1, p.gi_tpi1}, s2{p.x2, p.gi_q2, p.Cin2, p.gi_bm2 > 0 ? p.gi_bm2 : 1, p.gi_tpi2};
+      const int HWs = p.IH * p.IW;
+      const int g = tid / lpg, j = tid - g * lpg;
+      float a = 0.f, q2 = 0.f;
+      if (g < groups) gn_group_sums(s1, s2, img, HWs, Cg, g, j, lpg, a, q2);
+      for (int o = 1; o < lpg; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
+      if (g < groups && j == 0) {
+        const float n = (float)HWs * (float)Cg;
+        const float mu = a / n;
+        gtab[1024 + g] = mu;
+        gtab[1088 + g] = rsqrtf(fmaxf(q2 / n - mu * mu, 0.f) + p.gi_eps);
+      }
+    }
+    __syncthreads();
+    if (tid < p.Ctot) {                                      // (Ctot <= 512, host-checked)
+      const int gg = tid / Cg;
+      const float sc = my_gamma * gtab[1088 + gg];
+      gtab[tid] = sc;
+      gtab[512 + tid] = my_beta - gtab[1024 + gg] * sc;
+    }
+    __syncthreads();
+  }
+
+  if (loader) {
+    // ============================ loader waves: halo + weight DMA, GroupNorm of the landed halo ============================
+    const int lt = tid - NTC, lwave = wave - NTC / 64;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? (const void*)p.x2 : (const void*)p.x, p.x2 ? p.x2_bytes : p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const int rbase = lt >> 3;
+    const int kchunk = (lt & 7) ^ ((rbase >> 1) & 7);
+    int h_pix[HPL];
+    {
+      const FastDiv fd_w2 = {p.fd_halo.mul, p.fd_halo.shift};
+      const bool up = p.UH > 0;
+#pragma unroll
+      for (int ps = 0; ps < HPL; ++ps) {
+        const int hp = rbase + RPP * ps;
+        const int hy = fdiv(hp, fd_w2), hx = hp - hy * HW2;
+        const int gy = ty0 - 1 + hy, gx = hx - 1;
+        const bool ok = hp < halo_rows && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int sy = up ? (gy >> 1) : gy, sx = up ? (gx >> 1) : gx;
+        h_pix[ps] = ok ? (img * p.IH + sy) * p.IW + sx : -1;
+      }
+    }
+    unsigned b_off[W_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < W_PASSES; ++ps) {
+      const int row = min(n0 + rbase + RPP * ps, p.N - 1);
+      b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
+    }
+    int i_c = c_begin, i_tap = 0;
+    auto issue = [&](int item, int stage) {
+      const bool live = item < nitems;
+      char* bdst = Bring + stage * BSTAGE + lwave * 1024;
+      if (live && i_tap == 0) {
+        const int c0 = i_c << 6;
+        const bool src2 = c0 >= p.Cin;
+        const int Cs = src2 ? p.Cin2 : p.Cin;
+        const int soff = (c0 - (src2 ? p.Cin : 0)) * 2;
+        char* hdst = Hs + (i_c & 1) * HALO_BYTES + lwave * 1024;
+#pragma unroll
+        for (int ps = 0; ps < HPL; ++ps) {
+          const unsigned off = h_pix[ps] >= 0 ? (unsigned)h_pix[ps] * (unsigned)(Cs * 2) + kchunk * 16 : OOB;
+          if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+        }
+      }
+      const int ksoff = live ? (i_tap * p.Ctot + (i_c << 6)) * 2 : 0;
+#pragma unroll
+      for (int ps = 0; ps < W_PASSES; ++ps)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(bdst + ps * (RPP * 128)), 16, live ? b_off[ps] : OOB, ksoff, 0, 0);
+      if (live) {
+        if (++i_tap == 9) { i_tap = 0; ++i_c; }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s, s);
+    int st_fill = D;
+    int c_c = c_begin, c_tap = 0;
+    for (int item = 0; item < nitems; ++item) {
+      bool halo_young = false;
+#pragma unroll
+      for (int d = 1; d < D; ++d) {
+        const int t = c_tap + d;
+        halo_young = halo_young || ((t == 9 || t == 18) && item + d < nitems);
+      }
+      if (halo_young) wait_vmcnt<(D - 1) * W_PASSES + HPL>(); else wait_vmcnt<(D - 1) * W_PASSES>();
+      if constexpr (GNIN) {
+        if (c_tap == 0) {                                    // this item opens a chunk: normalise the pieces this thread DMA'd
+          const int cb = (c_c << 6) + kchunk * 8;
+          const f32x4 sc0 = *reinterpret_cast<const f32x4*>(gtab + cb), sc1 = *reinterpret_cast<const f32x4*>(gtab + cb + 4);
+          const f32x4 sh0 = *reinterpret_cast<const f32x4*>(gtab + 512 + cb), sh1 = *reinterpret_cast<const f32x4*>(gtab + 512 + cb + 4);
+          char* hb = Hs + (c_c & 1) * HALO_BYTES + lwave * 1024 + lane * 16;
+#pragma unroll
+          for (int ps = 0; ps < HPL; ++ps) {
+            if (h_pix[ps] >= 0) {
+              const bf16x8 v = *reinterpret_cast<const bf16x8*>(hb + ps * (RPP * 128));
+              bf16x8 o;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                float t = fmaf((float)v[k], k < 4 ? sc0[k & 3] : sc1[k & 3], k < 4 ? sh0[k & 3] : sh1[k & 3]);
+                if (p.gi_act == ALDM_ACT_SILU) t = silu_f(t);
+                o[k] = (bf16)t;
+              }
+              *reinterpret_cast<bf16x8*>(hb + ps * (RPP * 128)) = o;
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+      }
+      __builtin_amdgcn_s_barrier();                          // item handed over; the stage of item - 1 is free
+      issue(item + D, st_fill);
+      st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
+      if (++c_tap == 9) { c_tap = 0; ++c_c; }
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    return;                                                  // (an ended wave counts as arrived at every later barrier)
+  }
+
+  // ===================================== compute waves =====================================
+  const int wm = wave / WN, wn = wave % WN;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lrow = lane & 15, lq = lane >> 4;
+  int a_hp[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int pl = wm * (BM / WM) + i * 16 + lrow;
+    const int ly = fdiv(pl, p.fd_ow), lx = pl - ly * W;
+    a_hp[i] = ly * HW2 + lx;
+  }
+  {
+    int st = 0, c_c = c_begin, c_tap = 0, c_dy = 0, c_dx = 0;
+    for (int item = 0; item < nitems; ++item) {
+      __builtin_amdgcn_s_barrier();
+      const char* As = Hs + (c_c & 1) * HALO_BYTES;
+      const char* Bs = Bring + st * BSTAGE;
+      const int tap_off = c_dy * HW2 + c_dx;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ks * 4 + lq;
+        bf16x8 af[MI], wf[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int r = a_hp[i] + tap_off;
+          af[i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + swz(r, ch) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int r = wn * (BN / WN) + j * 16 + lrow;
+          wf[j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + swz(r, ch) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      st = (st + 1 == S) ? 0 : st + 1;
+      ++c_tap;
+      if (++c_dx == 3) { c_dx = 0; ++c_dy; }
+      if (c_tap == 9) { c_tap = 0; c_dy = 0; ++c_c; }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  IgemmDev q = p;
+  q.M = min(p.M, min(m0 + BM, (img + 1) * p.OHW));
+  q.qtile = tile_m;
+  igemm_epilogue<BM, BN, MI, NI, false, NTC, EPI>(q, acc, smem, false, m0, n0, wm * (BM / WM), wn * (BN / WN), lrow, lq, split, tid, nullptr);
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false, bool WS = false>
 int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128 + (GNIN ? (1024 + 128) * sizeof(float) : 0);
   constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds)
-  auto kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
+  static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds); one per instantiation (WS included)
+  auto kern = WS ? igemm_halo_ws_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN> : igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_halo")) return rc;
   const int rows_pt = BM / d.OW;
   if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
@@ -273,37 +516,58 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   dd.fd_tiles_n = make_fastdiv((unsigned)dd.tiles_n);
   dd.fd_halo = make_fastdiv((unsigned)(d.OW + 2));
   const int tpi = cdiv(d.OH, rows_pt);
-  dim3 grid(d.B * tpi * dd.tiles_n, 1, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dd);
+  dd.tiles_m = d.B * tpi * dd.tiles_n;                      // (split-K form) tiles per split: the divisor that peels the split off blockIdx.x
+  dd.fd_tiles_m = make_fastdiv((unsigned)dd.tiles_m);
+  dim3 grid(d.B * tpi * dd.tiles_n * (EPI == 3 ? d.splits : 1), 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(WS ? 768 : 512), lds, st, dd);
   return aldm_launch_status("igemm_halo");
 }
 
-template <int BM, int BN, int WM, int WN, int HP, int S>
+template <int BM, int BN, int WM, int WN, int HP, int S, bool WS = false>
 int launch_halo(const IgemmDev& d, hipStream_t st) {
+  if (d.splits > 1) {
+    if (d.gi_gamma) {
+      aldm_set_error("igemm_halo: gnin_* launches are not split");
+      return ALDM_E_UNSUPPORTED;
+    }
+    return launch_halo_v<BM, BN, WM, WN, HP, S, 3, false, WS>(d, st);
+  }
   if (d.gi_gamma) {                                          // GroupNorm of the input folded in: the ResnetBlock2D convolutions (lean epilogues)
     if (d.out_act != ALDM_ACT_NONE || d.post_act != ALDM_ACT_NONE) {
       aldm_set_error("igemm_halo: gnin_* launches take no output activation");
       return ALDM_E_UNSUPPORTED;
     }
-    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4, true>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1, true>(d, st);
+    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4, true, WS>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1, true, WS>(d, st);
   }
   if (d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE)
-    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1>(d, st);
-  return launch_halo_v<BM, BN, WM, WN, HP, S, 0>(d, st);
+    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4, false, WS>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1, false, WS>(d, st);
+  return launch_halo_v<BM, BN, WM, WN, HP, S, 0, false, WS>(d, st);
 }
 
 }  // namespace aldm_igemm_detail
 
-// tile: ALDM_TILE_HALO_128x128 or ALDM_TILE_HALO_64x128.  The caller (aldm_igemm) has validated the generic arguments.
+// tile: ALDM_TILE_HALO_128x128 / _64x128 or their wave-specialised forms (_WS).  The caller (aldm_igemm) has validated the generic arguments.
 int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, hipStream_t st) {
   using namespace aldm_igemm_detail;
   const bool ok = d.KH == 3 && d.KW == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh == 1 && d.dw == 1 &&
-                  d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.dilate == 0 && d.splits <= 1 &&
+                  d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.dilate == 0 &&
                   !d.ln_s && !d.geglu && d.x_bytes < 0x80000000u && d.x2_bytes < 0x80000000u &&
                   (d.UH == 0 || (d.UH == 2 * d.IH && d.UW == 2 * d.IW)) && d.OH == (d.UH ? d.UH : d.IH) && d.OW == (d.UW ? d.UW : d.IW);
   if (!ok) {
-    aldm_set_error("igemm_halo: needs a 3x3 / stride 1 / pad 1 conv on the LDS-DMA path (Cin %% 64 == 0, no gather activation, no split-K)");
+    aldm_set_error("igemm_halo: needs a 3x3 / stride 1 / pad 1 conv on the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
     return ALDM_E_UNSUPPORTED;
+  }
+  if (tile == ALDM_TILE_HALO_128x128_WS) {                  // 8 compute + 4 loader waves; ring 3 (4 where asked)
+    if ((128 / d.OW + 2) * (d.OW + 2) > 192) {
+      if (ring == 4) return launch_halo<128, 128, 4, 2, 5, 4, true>(d, st);
+      return launch_halo<128, 128, 4, 2, 5, 3, true>(d, st);
+    }
+    if (ring == 4) return launch_halo<128, 128, 4, 2, 3, 4, true>(d, st);
+    return launch_halo<128, 128, 4, 2, 3, 3, true>(d, st);
+  }
+  if (tile == ALDM_TILE_HALO_64x128_WS) {
+    if (ring == 4) return launch_halo<64, 128, 2, 4, 2, 4, true>(d, st);
+    return launch_halo<64, 128, 2, 4, 2, 3, true>(d, st);
   }
   if (tile == ALDM_TILE_HALO_128x128) {
     // halo rows the tile needs: (128 / OW + 2) image rows of OW + 2 pixels.  192 (three DMA passes) covers OW <= 16 -- the UNet's

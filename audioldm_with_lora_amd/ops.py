@@ -203,15 +203,15 @@ def pick_ring(tile, bm, bn, rp, nwg, ktiles):
     return max(2, min(want, fit))
 
 
-TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64), 12: (256, 128), 13: (64, 128), 14: (128, 64)}
-HALO_ROWS = {7: 320, 8: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip; 128x128: three or five DMA passes)
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 6: (128, 128), 7: (128, 128), 8: (64, 128), 9: (256, 128), 10: (64, 128), 11: (128, 64), 12: (256, 128), 13: (64, 128), 14: (128, 64), 15: (128, 128), 16: (64, 128)}
+HALO_ROWS = {7: 320, 8: 128, 15: 320, 16: 128}          # LDS halo capacity (rows) of the two halo tiles (csrc/igemm_halo.hip; 128x128: three or five DMA passes)
 
 
 def halo_tiles(OW, eligible):
     """Halo tiles able to take a 3x3/s1/p1 conv whose output is OW wide: BM a multiple of OW and the halo within capacity."""
     if not eligible:
         return []
-    return [t for t in (7, 8) if TILE_DIMS[t][0] % OW == 0 and (TILE_DIMS[t][0] // OW + 2) * (OW + 2) <= HALO_ROWS[t]]
+    return [t for t in (7, 8, 15, 16) if TILE_DIMS[t][0] % OW == 0 and (TILE_DIMS[t][0] // OW + 2) * (OW + 2) <= HALO_ROWS[t]]
 
 # ---- measured launch configurations ------------------------------------------------------------------------------
 # "Measure, don't guess": tools/autotune.py picks (tile, ring, splits) per distinct GEMM in two stages and writes
@@ -287,6 +287,12 @@ class Tuner:
                     cands.append((t, rg, sp))
         if forced_splits in (None, 1):
             cands += [(t, rg, 1) for t in halo for rg in (2, 3, 4)]
+            if can_split and " gi" not in key:              # the halo tiles split by 64-channel chunk (csrc/igemm_halo.hip)
+                nch = ktiles // 9
+                for t in halo:
+                    base = math.ceil(M / TILE_DIMS[t][0]) * math.ceil(pw.N / TILE_DIMS[t][1])
+                    cands += [(t, rg, sp) for sp in (2, 3, 4, 5, 6, 8, 10) for rg in (3, 4)
+                              if sp <= nch and base * sp <= 2560 and sp * M * pw.N * 4 <= (1 << 28)]
         max_sp = max(c[2] for c in cands)
         ws = _workspace(max_sp * M * pw.N * 4, device) if max_sp > 1 else None
         results = []
@@ -343,7 +349,7 @@ def save_tuned(path=TUNED_PATH):
                    "igemm": {k: list(v) for k, v in sorted(TUNED.items())}}, f, indent=0)
 
 
-TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8", 12: "256x128ws", 13: "64x128ws", 14: "128x64ws"}
+TILE_NAMES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 6: "128x128w8", 7: "halo128x128", 8: "halo64x128", 9: "256x128w8", 10: "64x128w8", 11: "128x64w8", 12: "256x128ws", 13: "64x128ws", 14: "128x64ws", 15: "halo128x128ws", 16: "halo64x128ws"}
 
 # Optional launch profiler (bench.py): a list that receives (label, flops, bytes, start_event, end_event, site) per C-ABI call.
 # Events are recorded on the stream the kernel is launched on.  SITE tags the launches of one fused-LoRA attention module
@@ -620,7 +626,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         if not gn_in_ok(x, x2, pw, stride, pad, dil, up_size, x3):
             raise _lib.AldmError("conv: gn_in needs a 3x3 / stride 1 / pad 1 launch that fits a halo tile and inputs with .qstats (gn_in_ok)")
         if tile not in HALO_ROWS:
-            tile, ring = (7 if (128 % OW == 0 and (128 // OW + 2) * (OW + 2) <= HALO_ROWS[7]) else 8), GNIN_RING
+            tile, ring = (15 if (128 % OW == 0 and (128 // OW + 2) * (OW + 2) <= HALO_ROWS[15]) else 16), GNIN_RING   # the loader waves normalise
         splits = 1
         gm_, bt_, a.gnin_groups, a.gnin_eps, a.gnin_act = gn_in
         a.gnin_gamma, a.gnin_beta = gm_.data_ptr(), bt_.data_ptr()

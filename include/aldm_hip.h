@@ -137,6 +137,8 @@ enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE
        /* 3x3 / stride-1 / pad-1 convs only: the workgroup keeps the input halo of BM/OW image rows in LDS and reads the
           nine taps from it (csrc/igemm_halo.hip); needs Cin % 64 == 0, BM % OW == 0, no split-K / LoRA / V^T */
        ALDM_TILE_HALO_128x128 = 7, ALDM_TILE_HALO_64x128 = 8,
+       ALDM_TILE_HALO_128x128_WS = 15, ALDM_TILE_HALO_64x128_WS = 16 /* the halo tiles with 8 compute + 4 loader waves (the loader waves also
+          apply gnin_*) */,
        ALDM_TILE_256x128_W8 = 9 /* 8-wave workgroup, 64x64 per wave: big-M plain convolutions (VAE, vocoder) */,
        ALDM_TILE_256x128_WS = 12 /* wave-specialised: 8 compute waves + 4 loader waves that only feed the LDS-DMA ring (csrc/igemm_ws.hip);
           plain big-M convolutions: LDS-DMA path, no LoRA / V^T / folded LayerNorm / fused 1x1 segment / GEGLU */,

@@ -59,7 +59,7 @@ def test_conv3x3(ops, B, Cin, Cout, H, W, stride, tile):
     close(to_nchw(y), want)
 
 
-@pytest.mark.parametrize("tile", [7, 8])
+@pytest.mark.parametrize("tile", [7, 8, 15, 16])     # 15 / 16: the wave-specialised forms (8 compute + 4 loader waves)
 @pytest.mark.parametrize("B,C1,C2,Cout,H,W,up", [
     (2, 128, 0, 128, 50, 16, False),      # level-0 shape, whole tiles
     (3, 64, 0, 128, 37, 16, False),       # ragged height: the last tile of every image is partial
@@ -104,8 +104,6 @@ def test_conv3x3_halo_rejects_unsupported(ops):
         ops.conv(x, pw1, tile=7)                                   # not a 3x3
     with pytest.raises(AldmError):
         ops.conv(x, pw3, pad=(1, 1), stride=(2, 2), tile=7)        # strided
-    with pytest.raises(AldmError):
-        ops.conv(x, pw3, pad=(1, 1), tile=7, splits=2)             # split-K
     x5 = nhwc(bf(torch.randn(1, 64, 12, 5, generator=g)))
     with pytest.raises(AldmError):
         ops.conv(x5, pw3, pad=(1, 1), tile=8)                      # width 5 does not divide the tile
@@ -373,7 +371,8 @@ def test_gn_silu_conv_out_one_launch(ops, B, H, tile):
 
 @pytest.mark.parametrize("B,H,C1,C2,N,res", [(2, 250, 128, 0, 128, True), (2, 250, 256, 128, 128, False), (1, 130, 128, 128, 128, False),
                                                (2, 250, 128, 0, 256, False)])
-def test_conv_applies_groupnorm_of_its_input(ops, B, H, C1, C2, N, res):
+@pytest.mark.parametrize("tile", [0, 15, 16])    # 0: the default halo tile; 15 / 16: the loader waves normalise the halo
+def test_conv_applies_groupnorm_of_its_input(ops, B, H, C1, C2, N, res, tile):
     """ops.conv(gn_in=): ResnetBlock2D norm1 / norm2 + SiLU inside the consuming convolution's halo tile (statistics from the
     producers' tables, concatenated sources, groups that straddle the concatenation) against torch and against the two launches."""
     g = torch.Generator().manual_seed(43)
@@ -396,7 +395,7 @@ def test_conv_applies_groupnorm_of_its_input(ops, B, H, C1, C2, N, res):
     rb = torch.randn(B, N, generator=g)
     assert ops.gn_in_ok(y1, y2, pw)
     kw = dict(pad=(1, 1), rowbias=rb.to(DEV), rowbias_ld=N, res=(nhwc(r) if res else None))
-    got = ops.conv(y1, pw, x2=y2, gn_in=(gm.to(DEV), bt.to(DEV), 32, 1e-5, 1), qstats=True, **kw)
+    got = ops.conv(y1, pw, x2=y2, gn_in=(gm.to(DEV), bt.to(DEV), 32, 1e-5, 1), qstats=True, tile=tile, **kw)
     assert getattr(got, "qstats", None) is not None                       # and it hands ITS statistics on
     xin = torch.cat([to_nchw(y1)] + ([to_nchw(y2)] if C2 else []), 1)
     a = bf(F.silu(F.group_norm(xin, 32, gm, bt, 1e-5)))
@@ -629,6 +628,28 @@ def test_conv3x3_eight_wave_small_tiles(ops, tile, splits, ring):
     want = F.conv2d(torch.cat([x, x2], 1), w, b, padding=1) + r
     y = ops.conv(nhwc(x), ops.pack_conv(w.to(DEV), b.to(DEV)), x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=tile, ring=ring, splits=splits)
     close(to_nchw(y), want)
+
+
+@pytest.mark.parametrize("tile,shape,splits", [(7, (8, 32, 2), 10), (7, (8, 32, 2), 3), (7, (3, 63, 4), 4), (8, (3, 63, 4), 5), (7, (2, 125, 8), 2),
+                                               (8, (2, 125, 8), 2), (7, (2, 37, 16), 5),
+                                               (15, (8, 32, 2), 10), (15, (3, 63, 4), 4), (16, (3, 63, 4), 5), (15, (2, 125, 8), 2), (16, (2, 125, 8), 3),
+                                               (15, (2, 37, 16), 5)])
+def test_conv3x3_halo_split_k(ops, tile, shape, splits):
+    """split-K on the halo tiles (by 64-channel chunk, partial tiles in the workspace slabs): == torch on the latent geometries of every UNet
+    level (2 / 4 / 8 / 16 wide; image heights that do not fill the last tile), two sources + residual, more splits asked than chunks
+    divide into, and the reduce deferred to the GroupNorm that follows."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(140 + tile + splits)
+    x, x2 = bf(torch.randn(B, 192, H, W, generator=g)), bf(torch.randn(B, 128, H, W, generator=g))
+    w, b = bf(torch.randn(256, 320, 3, 3, generator=g) * 0.03), torch.randn(256, generator=g)
+    r = bf(torch.randn(B, 256, H, W, generator=g))
+    want = F.conv2d(torch.cat([x, x2], 1), w, b, padding=1) + r
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    y = ops.conv(nhwc(x), pw, x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=tile, splits=splits)
+    close(to_nchw(y), want)
+    gamma, beta = torch.randn(256, generator=g).to(DEV), torch.randn(256, generator=g).to(DEV)
+    yn = ops.conv(nhwc(x), pw, x2=nhwc(x2), pad=(1, 1), res=nhwc(r), tile=tile, splits=splits, gn=(gamma, beta, 32, 1e-5, ops.ACT_SILU))
+    close(to_nchw(yn), F.silu(F.group_norm(want, 32, gamma.cpu(), beta.cpu(), 1e-5)), rtol=3e-2)
 
 
 @pytest.mark.parametrize("tile,ring", [(13, 3), (13, 4), (14, 3), (14, 4), (13, 2), (14, 2)])   # ring 2 = register-staged loaders

@@ -32,7 +32,9 @@ def key_m(key):
 def eligible(key):
     if not re.match(r"M(\d+) N(\d+) ", key) or any(t not in key for t in (" f1", " r0 ", " vt0 ", " g0 ", " ln0 ")):
         return False
-    if any(t in key for t in (" gi", " lp", " rs", " vd")) or (family != "all" and " k3x3 s1 " not in key):
+    if family == "halo" and " gi" in key and " d0 " in key:
+        return True                                         # GroupNorm-of-the-input launches: halo tiles only, never split
+    if any(t in key for t in (" gi", " lp", " rs", " vd")) or (family != "all" and " k3x3 s1 " not in key) or (family == "halo" and " d0 " not in key):
         return False
     M = key_m(key)
     return (256 <= M <= 8192) if family == "small" else M > 8192 if family == "big" else M >= 256
@@ -109,14 +111,29 @@ base_used = dict(USED)
 SMALL = [("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1), ("128x64ws r4", 14, 4, 1), ("64x128ws r3 /2", 13, 3, 2), ("128x64ws r3 /2", 14, 3, 2),
          ("128x64ws r4 /2", 14, 4, 2)]
 BIG = [("256x128ws", 12, 3, 1), ("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1)]
-rules = SMALL if family == "small" else BIG if family == "big" else SMALL + [("256x128ws", 12, 3, 1)]
+# the halo tiles with split-K by channel chunk: the key's current split count, half of it, twice it
+HALO = [("halo128ws", 15, 3, 1), ("halo128ws /2", 15, 3, 2), ("halo128ws x2", 15, 3, 0.5), ("halo64ws", 16, 3, 1), ("halo64ws /2", 16, 3, 2),
+        ("halo64ws x2", 16, 3, 0.5), ("halo128ws 1", 15, 3, 1000), ("halo64ws 1", 16, 3, 1000), ("halo128ws r4", 15, 4, 1)]
+rules = SMALL if family == "small" else BIG if family == "big" else HALO if family == "halo" else SMALL + [("256x128ws", 12, 3, 1)]
 for name, tile, ring, spdiv in rules:
     ov = {}
     for k in keys:
         sp = base_used[k][2]
+        if tile in (7, 8, 15, 16):
+            ow = int(re.search(r" ow(\d+)", k).group(1))
+            if tile not in ops.halo_tiles(ow, True) or re.search(r" e\d+\+\d+", k):
+                continue
+            nch = sum(int(v) for v in re.search(r" C(\d+)\+(\d+) ", k).groups()) // 64
+            nsp = 1 if " gi" in k else max(1, min(nch, int(round(sp / spdiv))))
+            if (nsp == sp and spdiv != 1) or (tile, ring, nsp) == tuple(base_used[k]):
+                continue
+            ov[k] = (tile, ring, nsp)
+            continue
         if (spdiv > 1 and sp < 2 * spdiv) or (tile == 12 and key_m(k) <= 8192):
             continue
         ov[k] = (tile, ring, max(1, sp // spdiv))
+    if not ov:
+        continue
     try:
         pk, tot, span = measure(ov)
     except Exception as e:                                  # a key the tile refuses: drop the variant, say why

@@ -30,6 +30,24 @@ def run(name, B, H, W, Cin, Cout, cfgs, nrot=8):
             best = min(best, e0.elapsed_time(e1) / (3 * nrot))
         print(f"{name} tile {ops.TILE_NAMES[tile]:10s} ring {ring} splits {sp:2d}: {best * 1e3:7.2f} us (conv + reduce){'' if same else '  MISMATCH'}", flush=True)
 
+if len(sys.argv) > 1 and sys.argv[1] == "halows":   # wave-specialised halo tiles (15, 16) against the plain halo tiles (7, 8)
+    run("M512 N640 K5760", 8, 32, 2, 640, 640, [(14, 4, 6), (7, 3, 5), (15, 3, 5), (15, 4, 5), (15, 3, 10)])
+    run("M2016 N384 K3456", 8, 63, 4, 384, 384, [(13, 3, 4), (7, 3, 3), (15, 3, 3), (15, 3, 6), (8, 3, 2), (16, 3, 2), (16, 3, 3), (16, 4, 3)])
+    run("M2016 N384 K9216(C1024)", 8, 63, 4, 1024, 384, [(7, 3, 4), (15, 3, 4), (15, 4, 4), (15, 3, 8), (16, 3, 4)])
+    run("M8000 N256 K2304", 8, 125, 8, 256, 256, [(8, 3, 1), (16, 3, 1), (16, 4, 1), (7, 3, 1), (15, 3, 1), (15, 3, 2), (16, 3, 2)])
+    run("M8000 N256 K4608", 8, 125, 8, 512, 256, [(7, 3, 2), (15, 3, 2), (15, 4, 2), (16, 3, 2), (15, 3, 4)])
+    run("M32000 N128 K1152", 8, 250, 16, 128, 128, [(7, 3, 1), (15, 3, 1), (15, 4, 1), (16, 3, 1)])
+    run("M32000 N256 K2304", 8, 250, 16, 256, 256, [(7, 3, 1), (15, 3, 1), (15, 4, 1), (12, 3, 1)])
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "halo":   # split-K halo tiles against the adopted wave-specialised tiles
+    run("M512 N640 K5760", 8, 32, 2, 640, 640, [(14, 4, 6), (7, 3, 10), (7, 3, 5), (7, 4, 10), (7, 3, 4)])
+    run("M512 N1280 K11520", 8, 32, 2, 1280, 1280, [(14, 4, 3), (7, 3, 10), (7, 3, 5), (7, 3, 4), (7, 4, 5)])
+    run("M2016 N384 K3456", 8, 63, 4, 384, 384, [(13, 3, 4), (7, 3, 6), (7, 3, 3), (7, 4, 6), (8, 3, 6), (8, 3, 3), (8, 4, 3), (8, 3, 2)])
+    run("M2016 N384 K9216(C1024)", 8, 63, 4, 1024, 384, [(13, 3, 4), (7, 3, 8), (7, 3, 6), (7, 3, 4), (8, 3, 4), (8, 3, 8)])
+    run("M8000 N256 K2304", 8, 125, 8, 256, 256, [(13, 3, 1), (7, 3, 1), (7, 3, 2), (7, 4, 2), (7, 3, 4), (8, 3, 1), (8, 3, 2), (8, 4, 2)])
+    run("M8000 N256 K4608", 8, 125, 8, 512, 256, [(13, 3, 2), (7, 3, 2), (7, 3, 4), (8, 3, 2), (8, 3, 4)])
+    run("M32000 N128 K1152", 8, 250, 16, 128, 128, [(7, 3, 1), (7, 3, 2), (12, 3, 1)])
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "rs":   # register-staged loaders (ring 2) against LDS-DMA loaders (ring 3)
     run("M512 N640 K5760", 8, 32, 2, 640, 640, [(11, 3, 6), (14, 3, 6), (14, 4, 6), (14, 2, 6), (13, 3, 6), (13, 2, 6), (14, 2, 4), (14, 2, 3)])
     run("M512 N1280 K11520", 8, 32, 2, 1280, 1280, [(14, 4, 3), (14, 2, 3), (14, 2, 6), (13, 2, 3)])
