@@ -343,7 +343,7 @@ TRAIN_FAMILIES = (("attention_bwd", ("attn_bwd",)), ("attention_fwd", ("attentio
                   ("gemm_lora_site", ("igemm_pipe_kernel<64, 64, 2, 2, 32", "igemm_pipe_kernel<128, 64, 2, 2, 32", "igemm_pipe_kernel<64, 128, 2, 2, 32",
                                       "igemm_pipe_kernel<128, 128, 2, 2, 32", "igemm_pipe_kernel<64, 64, 2, 2, 64", "igemm_pipe_kernel<128, 64, 2, 2, 64",
                                       "igemm_pipe_kernel<64, 128, 2, 2, 64", "igemm_pipe_kernel<128, 128, 2, 2, 64", "pgemm_kernel")),
-                  ("gemm", ("igemm_pipe_kernel", "igemm_kernel", "igemm_halo_kernel")), ("splitk_reduce", ("igemm_reduce",)),
+                  ("gemm", ("igemm_pipe_kernel", "igemm_kernel", "igemm_halo_kernel", "igemm_halo_ws_kernel", "igemm_ws_kernel")), ("splitk_reduce", ("igemm_reduce",)),
                   ("groupnorm_bwd", ("groupnorm_bwd",)), ("groupnorm_fwd", ("groupnorm", "gn_silu")),
                   ("layernorm_geglu", ("layernorm", "geglu")), ("lora_grad", ("tn_mfma", "tn_small", "lora_pack")),
                   ("transpose", ("transpose_tokens",)), ("optimizer", ("adamw",)))

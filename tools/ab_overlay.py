@@ -98,7 +98,38 @@ def measure(overlay):
     return per_key, sum(r[5] for r in j), span
 
 
-if workload == "train":
+def measure_vae(overlay, total=False):
+    """AutoencoderKL.decode of 4 x 10 s latents, eager, hipEvent pairs queued behind a sleep kernel (bench.py times the same call)."""
+    from audioldm_with_lora_amd.vae import AutoencoderKL
+    ops.TUNED.clear(); ops.TUNED.update(BASE); ops.TUNED.update(overlay)
+    global _vae
+    if "_vae" not in globals():
+        torch.manual_seed(0)
+        _vae = AutoencoderKL().cuda()
+    z = torch.randn(4, 250, 16, 8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)).to(torch.bfloat16)
+    for _ in range(2):
+        _vae.decode_nhwc(z)
+    torch.cuda.synchronize()
+    ops.PROFILE, ops.KEYLOG = [], []
+    ops.sleep_us(100000)
+    _vae.decode_nhwc(z)
+    torch.cuda.synchronize()
+    rows, keylog, ops.PROFILE, ops.KEYLOG = ops.PROFILE, dict(ops.KEYLOG), None, None
+    per_key, tot = {}, 0.0
+    for i, r in enumerate(rows):
+        us = r[3].elapsed_time(r[4]) * 1e3
+        tot += us
+        k, cfg = keylog.get(i, (None, None))
+        if k is not None:
+            per_key[k] = per_key.get(k, 0.0) + us
+            USED[k] = cfg
+    return per_key, tot, tot
+
+
+if workload == "vae":
+    measure = lambda ov, total=False: measure_vae(ov, total)
+    base_keys, base_tot, base_span = measure({})
+elif workload == "train":
     unet, _ = bench.build_unet(8)
     infer_measure, measure = measure, (lambda ov, total=False: measure_train(ov, total))
     base_keys, base_tot, base_span = measure({}, total=True)
@@ -148,7 +179,7 @@ for k in keys:
     print(f"{k:100s} {line}  -> {best}")
     if best != "base" and variants[best][0][k] < 0.985 * base_keys[k]:
         patch[k] = list(variants[best][1][k])
-pk, tot, span = measure({k: tuple(v) for k, v in patch.items()}, True) if workload == "train" else measure({k: tuple(v) for k, v in patch.items()})
+pk, tot, span = measure({k: tuple(v) for k, v in patch.items()}, True) if workload != "infer" else measure({k: tuple(v) for k, v in patch.items()})
 print(f"merged overlay ({len(patch)} keys): kernel time {tot:.1f} us (base {base_tot:.1f}), span {span:.1f} us (base {base_span:.1f})")
 with open(out_path, "w") as f:
     json.dump(patch, f, indent=0)
