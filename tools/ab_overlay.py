@@ -18,7 +18,7 @@ from audioldm_with_lora_amd.scheduler import DDIMScheduler
 out_path = sys.argv[1]
 family = sys.argv[2] if len(sys.argv) > 2 else "small"
 workload = sys.argv[3] if len(sys.argv) > 3 else "infer"
-B = 4
+B = int(os.environ.get("ALDM_AB_BATCH", "4"))
 unet, _ = bench.build_unet(4)
 lat, pe, ne = bench.synth_inputs(B, 250, 16)
 BASE = dict(ops.TUNED)
