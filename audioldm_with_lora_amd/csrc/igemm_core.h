@@ -56,7 +56,6 @@ struct IgemmDev {
   int vt_col0, vt_ld; long long vt_bs; int vt_dual;
   int splits, kt_per_split, nkt;
   int tiles_n;
-  int ws_rows;                // rows of one split-K slab of the workspace (= the launch's M; the halo tiles cut p.M per image for the bound checks)
   int tiles_m, nwg, xmap;     // 1-D grid of tiles_m * tiles_n * splits workgroups; xmap: work item -> XCD order (see igemm_work_item)
   FastDiv fd_tiles_m, fd_splits;
   unsigned x_bytes, x2_bytes, w_bytes, la_bytes, lb_bytes;
@@ -72,6 +71,8 @@ struct IgemmDev {
   // GroupNorm (+ SiLU) of the input folded into the halo gather (igemm_halo.hip, GNIN instantiations); gi_gamma == nullptr: off
   const float* gi_gamma; const float* gi_beta; const float* gi_q1; const float* gi_q2;
   int gi_bm1, gi_tpi1, gi_bm2, gi_tpi2, gi_groups, gi_act; float gi_eps;
+  int ws_rows;                // rows of one split-K slab of the workspace (= the launch's M; the halo tiles cut p.M per image for the bound checks).
+                              // LAST on purpose: a new member anywhere above shifts the scalar-load groups of every kernel's prologue
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }

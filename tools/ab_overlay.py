@@ -143,8 +143,8 @@ SMALL = [("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1), ("128x64ws r4", 1
          ("128x64ws r4 /2", 14, 4, 2)]
 BIG = [("256x128ws", 12, 3, 1), ("64x128ws r3", 13, 3, 1), ("128x64ws r3", 14, 3, 1)]
 # the halo tiles with split-K by channel chunk: the key's current split count, half of it, twice it
-HALO = [("halo128ws", 15, 3, 1), ("halo128ws /2", 15, 3, 2), ("halo128ws x2", 15, 3, 0.5), ("halo64ws", 16, 3, 1), ("halo64ws /2", 16, 3, 2),
-        ("halo64ws x2", 16, 3, 0.5), ("halo128ws 1", 15, 3, 1000), ("halo64ws 1", 16, 3, 1000), ("halo128ws r4", 15, 4, 1)]
+HALO = [(f"{n}{sfx}", t, 3, d) for n, t in (("halo128ws", 15), ("halo64ws", 16), ("halo128", 7), ("halo64", 8))
+        for sfx, d in (("", 1), (" /2", 2), (" x2", 0.5), (" 1", 1000))] + [("halo128ws r4", 15, 4, 1), ("halo64ws r4", 16, 4, 1)]
 rules = SMALL if family == "small" else BIG if family == "big" else HALO if family == "halo" else SMALL + [("256x128ws", 12, 3, 1)]
 for name, tile, ring, spdiv in rules:
     ov = {}
