@@ -183,7 +183,10 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
     case ALDM_TILE_HALO_128x128_WS:
     case ALDM_TILE_HALO_64x128_WS:
       // (qstat_out is fine with the halo tiles: they are image-aligned, slot 0)
-      if (p->Rp || vt || p->rowstat_out || p->x3) { aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics / second-source segment"); return ALDM_E_UNSUPPORTED; }
+      if (p->Rp || vt || p->rowstat_out || (p->x3 && tile != ALDM_TILE_HALO_128x128_WS && tile != ALDM_TILE_HALO_64x128_WS)) {
+        aldm_set_error("igemm: the halo tiles take no LoRA / V^T / row statistics (and a second-source segment only in the wave-specialised forms)");
+        return ALDM_E_UNSUPPORTED;
+      }
       if (d.splits > 1) {   // split-K by whole 64-channel chunks: a chunk's halo serves its nine taps in one workgroup
         const int nch = (d.Cin + d.Cin2) / BK;
         const int cps = cdiv(nch, d.splits > nch ? nch : d.splits);

@@ -271,7 +271,12 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
 // DMA'd a piece normalises it once it has landed, before the barrier that releases the chunk).  Per tap the compute waves then go from
 // the barrier straight into the fragment reads and MFMAs: no DMA issue stall and no GroupNorm arithmetic on the waves that multiply
 // (igemm_ws.hip has the measurements behind the split).  Same LDS images, cursors, split-K rule and epilogue as igemm_halo_kernel.
-template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false>
+// EXT: the fused 1x1 second-source segment (conv2 + conv_shortcut of a ResnetBlock2D as ONE GEMM, aldm_igemm x3 | x4): after its 3x3
+// chunks a workgroup walks its share of the segment's 64-channel chunks, each ONE item -- the chunk's pixels arrive as a halo image
+// of x3 / x4 (same gather, the border rows are the price of one code path) and are read at the centre tap.  Every such item opens a
+// halo, and the loaders run two items ahead, so the halo buffers are THREE (u % 3) and the ring depth is fixed at 3.  Split-K: a split
+// takes its main chunks as before plus an even share of the segment's chunks.
+template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false, bool EXT = false>
 __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(IgemmDev)>();
@@ -284,12 +289,14 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
   constexpr int HALO_BYTES = HP * 64 * 128;
   constexpr int BSTAGE = BN * 128;
   constexpr unsigned OOB = 0x80000000u;
-  static_assert((D - 1) * W_PASSES + HPL < 64, "vmcnt immediate");
+  static_assert((D - 1) * (W_PASSES + HPL) < 64, "vmcnt immediate");
+  static_assert(!EXT || (S == 3 && !GNIN), "fused-shortcut form: ring 3, no gnin_*");
+  constexpr int NB = EXT ? 3 : 2;                       // halo buffers
 
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][halo: HP*64 x 128 B] [S][B: BN x 128 B] [GNIN tables]
   char* const Hs = smem;
-  char* const Bring = smem + 2 * HALO_BYTES;
-  float* const gtab = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + S * BSTAGE);
+  char* const Bring = smem + NB * HALO_BYTES;
+  float* const gtab = reinterpret_cast<float*>(smem + NB * HALO_BYTES + S * BSTAGE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,7 +317,13 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
   const int nchunks = p.Ctot >> 6;
   const int c_begin = EPI == 3 ? split * (p.kt_per_split / 9) : 0;
   const int c_end = EPI == 3 ? min(nchunks, c_begin + p.kt_per_split / 9) : nchunks;
-  const int nitems = (c_end - c_begin) * 9;
+  // the segment's chunks of this workgroup: [e_begin, e_end) of C3tot / 64
+  const int next = EXT ? (p.C3tot >> 6) : 0;
+  const int eps = EPI == 3 ? (next + p.splits - 1) / p.splits : next;
+  const int e_begin = EPI == 3 ? min(next, split * eps) : 0;
+  const int e_end = min(next, e_begin + eps);
+  const int nmain = (c_end - c_begin) * 9;
+  const int nitems = nmain + (e_end - e_begin);
 
   if constexpr (GNIN) {
     // per-channel (scale, shift) from the producers' statistics tables: the compute waves (idle until the first tile lands) do the
@@ -372,29 +385,47 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
       const int row = min(n0 + rbase + RPP * ps, p.N - 1);
       b_off[ps] = (unsigned)row * (unsigned)p.Kpad * 2u + kchunk * 16;
     }
-    int i_c = c_begin, i_tap = 0;
+    int i_c = c_begin, i_tap = 0, i_u = 0;              // chunk, tap, unit counter (a unit = one halo image: 9 taps, or 1 in the segment)
+    bool i_ext = EXT && nmain == 0;
+    if (i_ext) i_c = e_begin;
     auto issue = [&](int item, int stage) {
       const bool live = item < nitems;
       char* bdst = Bring + stage * BSTAGE + lwave * 1024;
       if (live && i_tap == 0) {
         const int c0 = i_c << 6;
-        const bool src2 = c0 >= p.Cin;
-        const int Cs = src2 ? p.Cin2 : p.Cin;
-        const int soff = (c0 - (src2 ? p.Cin : 0)) * 2;
-        char* hdst = Hs + (i_c & 1) * HALO_BYTES + lwave * 1024;
+        char* hdst = Hs + (EXT ? i_u % 3 : (i_c & 1)) * HALO_BYTES + lwave * 1024;
+        if (EXT && i_ext) {                                  // a chunk of x3 | x4 (output geometry: h_pix is the same pixel index)
+          const bool s4 = c0 >= p.Cin3;
+          const int Cs = s4 ? p.Cin4 : p.Cin3;
+          const int soff = (c0 - (s4 ? p.Cin3 : 0)) * 2;
+          const __amdgpu_buffer_rsrc_t rs_e = s4 ? make_rsrc(p.x4, p.x4_bytes) : make_rsrc(p.x3, p.x3_bytes);
 #pragma unroll
-        for (int ps = 0; ps < HPL; ++ps) {
-          const unsigned off = h_pix[ps] >= 0 ? (unsigned)h_pix[ps] * (unsigned)(Cs * 2) + kchunk * 16 : OOB;
-          if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
-          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+          for (int ps = 0; ps < HPL; ++ps) {
+            const unsigned off = h_pix[ps] >= 0 ? (unsigned)h_pix[ps] * (unsigned)(Cs * 2) + kchunk * 16 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+          }
+        } else {
+          const bool src2 = c0 >= p.Cin;
+          const int Cs = src2 ? p.Cin2 : p.Cin;
+          const int soff = (c0 - (src2 ? p.Cin : 0)) * 2;
+#pragma unroll
+          for (int ps = 0; ps < HPL; ++ps) {
+            const unsigned off = h_pix[ps] >= 0 ? (unsigned)h_pix[ps] * (unsigned)(Cs * 2) + kchunk * 16 : OOB;
+            if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(hdst + ps * (RPP * 128)), 16, off, soff, 0, 0);
+          }
         }
       }
-      const int ksoff = live ? (i_tap * p.Ctot + (i_c << 6)) * 2 : 0;
+      const int ksoff = !live ? 0 : (EXT && i_ext) ? (9 * p.Ctot + (i_c << 6)) * 2 : (i_tap * p.Ctot + (i_c << 6)) * 2;
 #pragma unroll
       for (int ps = 0; ps < W_PASSES; ++ps)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(bdst + ps * (RPP * 128)), 16, live ? b_off[ps] : OOB, ksoff, 0, 0);
       if (live) {
-        if (++i_tap == 9) { i_tap = 0; ++i_c; }
+        if (EXT && i_ext) { ++i_c; ++i_u; }
+        else if (++i_tap == 9) {
+          i_tap = 0; ++i_c; ++i_u;
+          if (EXT && i_c == c_end) { i_ext = true; i_c = e_begin; }
+        }
       }
     };
 #pragma unroll
@@ -402,13 +433,17 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
     int st_fill = D;
     int c_c = c_begin, c_tap = 0;
     for (int item = 0; item < nitems; ++item) {
-      bool halo_young = false;
+      // how many of the D - 1 younger items in flight carry a halo: an item does if it opens a unit (tap 0 of a chunk; every item of the segment)
+      int young = 0;
 #pragma unroll
       for (int d = 1; d < D; ++d) {
-        const int t = c_tap + d;
-        halo_young = halo_young || ((t == 9 || t == 18) && item + d < nitems);
+        const int t = c_tap + d, it = item + d;
+        const bool opens = it < nitems && (it >= nmain || (it < nmain && (t == 9 || t == 18)));
+        young += opens ? 1 : 0;
       }
-      if (halo_young) wait_vmcnt<(D - 1) * W_PASSES + HPL>(); else wait_vmcnt<(D - 1) * W_PASSES>();
+      if (young == 0) wait_vmcnt<(D - 1) * W_PASSES>();
+      else if (young == 1 || D < 3) wait_vmcnt<(D - 1) * W_PASSES + HPL>();
+      else wait_vmcnt<(D - 1) * W_PASSES + (D > 2 ? 2 : 1) * HPL>();
       if constexpr (GNIN) {
         if (c_tap == 0) {                                    // this item opens a chunk: normalise the pieces this thread DMA'd
           const int cb = (c_c << 6) + kchunk * 8;
@@ -435,7 +470,7 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
       __builtin_amdgcn_s_barrier();                          // item handed over; the stage of item - 1 is free
       issue(item + D, st_fill);
       st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
-      if (++c_tap == 9) { c_tap = 0; ++c_c; }
+      if (item < nmain && ++c_tap == 9) { c_tap = 0; ++c_c; }
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -458,12 +493,13 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
     a_hp[i] = ly * HW2 + lx;
   }
   {
-    int st = 0, c_c = c_begin, c_tap = 0, c_dy = 0, c_dx = 0;
+    int st = 0, c_c = c_begin, c_tap = 0, c_dy = 0, c_dx = 0, c_u = 0;
     for (int item = 0; item < nitems; ++item) {
       __builtin_amdgcn_s_barrier();
-      const char* As = Hs + (c_c & 1) * HALO_BYTES;
+      const bool seg = EXT && item >= nmain;                 // (uniform) an item of the 1x1 segment: centre tap of its own halo image
+      const char* As = Hs + (EXT ? c_u % 3 : (c_c & 1)) * HALO_BYTES;
       const char* Bs = Bring + st * BSTAGE;
-      const int tap_off = c_dy * HW2 + c_dx;
+      const int tap_off = seg ? HW2 + 1 : c_dy * HW2 + c_dx;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int ch = ks * 4 + lq;
@@ -484,9 +520,10 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
           for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
       st = (st + 1 == S) ? 0 : st + 1;
+      if (seg) { ++c_u; continue; }
       ++c_tap;
       if (++c_dx == 3) { c_dx = 0; ++c_dy; }
-      if (c_tap == 9) { c_tap = 0; c_dy = 0; ++c_c; }
+      if (c_tap == 9) { c_tap = 0; c_dy = 0; ++c_c; ++c_u; }
     }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -498,13 +535,17 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false, bool WS = false>
+template <int BM, int BN, int WM, int WN, int HP, int S, int EPI, bool GNIN = false, bool WS = false, bool EXT = false>
 int launch_halo_v(const IgemmDev& d, hipStream_t st) {
-  constexpr size_t lds_loop = 2 * (size_t)HP * 64 * 128 + (size_t)S * BN * 128 + (GNIN ? (1024 + 128) * sizeof(float) : 0);
+  static_assert(!EXT || WS, "the fused-shortcut form exists for the wave-specialised kernel only");
+  constexpr size_t lds_loop = (EXT ? 3 : 2) * (size_t)HP * 64 * 128 + (size_t)S * BN * 128 + (GNIN ? (1024 + 128) * sizeof(float) : 0);
   constexpr size_t lds = lds_loop > (size_t)EpiCfg<BM, BN>::BYTES ? lds_loop : (size_t)EpiCfg<BM, BN>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static unsigned long long attr_done = 0;   // per-device bit mask (aldm_set_max_lds); one per instantiation (WS included)
-  auto kern = WS ? igemm_halo_ws_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN> : igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
+  void (*kern)(const IgemmDev);
+  if constexpr (EXT) kern = igemm_halo_ws_kernel<BM, BN, WM, WN, HP, S, EPI, false, true>;
+  else if constexpr (WS) kern = igemm_halo_ws_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
+  else kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_halo")) return rc;
   const int rows_pt = BM / d.OW;
   if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
@@ -521,6 +562,18 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   dim3 grid(d.B * tpi * dd.tiles_n * (EPI == 3 ? d.splits : 1), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(WS ? 768 : 512), lds, st, dd);
   return aldm_launch_status("igemm_halo");
+}
+
+template <int BM, int BN, int WM, int WN, int HP, int S>
+int launch_halo_ext(const IgemmDev& d, hipStream_t st) {     // conv2 + conv_shortcut as one GEMM (x3 | x4 segment), wave-specialised form
+  if (d.gi_gamma) {
+    aldm_set_error("igemm_halo: gnin_* launches take no second-source segment");
+    return ALDM_E_UNSUPPORTED;
+  }
+  if (d.splits > 1) return launch_halo_v<BM, BN, WM, WN, HP, S, 3, false, true, true>(d, st);
+  if (d.out_act == ALDM_ACT_NONE && d.post_act == ALDM_ACT_NONE)
+    return d.qstat ? launch_halo_v<BM, BN, WM, WN, HP, S, 4, false, true, true>(d, st) : launch_halo_v<BM, BN, WM, WN, HP, S, 1, false, true, true>(d, st);
+  return launch_halo_v<BM, BN, WM, WN, HP, S, 0, false, true, true>(d, st);
 }
 
 template <int BM, int BN, int WM, int WN, int HP, int S, bool WS = false>
@@ -555,6 +608,13 @@ int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, h
                   (d.UH == 0 || (d.UH == 2 * d.IH && d.UW == 2 * d.IW)) && d.OH == (d.UH ? d.UH : d.IH) && d.OW == (d.UW ? d.UW : d.IW);
   if (!ok) {
     aldm_set_error("igemm_halo: needs a 3x3 / stride 1 / pad 1 conv on the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
+    return ALDM_E_UNSUPPORTED;
+  }
+  if (d.C3tot > 0) {                                          // the fused 1x1 segment: wave-specialised tiles, three-pass halo at most
+    const bool fits = d.UH == 0 && d.C3tot % 64 == 0 && d.Cin3 % 64 == 0 && d.x3_bytes < 0x80000000u && d.x4_bytes < 0x80000000u;
+    if (fits && tile == ALDM_TILE_HALO_128x128_WS && (128 / d.OW + 2) * (d.OW + 2) <= 192) return launch_halo_ext<128, 128, 4, 2, 3, 3>(d, st);
+    if (fits && tile == ALDM_TILE_HALO_64x128_WS) return launch_halo_ext<64, 128, 2, 4, 2, 3>(d, st);
+    aldm_set_error("igemm_halo: the second-source segment needs a wave-specialised halo tile whose halo fits three DMA passes (OW >= 8 at 128 rows)");
     return ALDM_E_UNSUPPORTED;
   }
   if (tile == ALDM_TILE_HALO_128x128_WS) {                  // 8 compute + 4 loader waves; ring 3 (4 where asked)

@@ -607,8 +607,11 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
-                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None and x3 is None
+                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None
                           and (up_size is None or up_size == (2 * IH, 2 * IW)))
+        if x3 is not None:      # conv2 + conv_shortcut as one GEMM: the wave-specialised halo tiles only, three-pass halo, no up-sampling
+            halo = [t for t in halo if t in (15, 16) and up_size is None and C3 % 64 == 0 and C4 % 64 == 0
+                    and (TILE_DIMS[t][0] // OW + 2) * (OW + 2) <= (192 if t == 15 else 128)]
         cfg = TUNED.get(key)
         if cfg is None and TUNED_LEGACY_KEYS:           # tables written before the geometry suffix existed
             cfg = TUNED.get(tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None,
@@ -620,6 +623,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             cfg = TUNER.choose(key, a, M, pw, ktiles, can_split and splits is None, splits, fast_path, vt is not None, x.device, halo)
         if cfg is not None:
             tile, ring, splits = cfg
+            if x3 is not None and tile in HALO_ROWS:
+                ring = 3                                    # (the fused-shortcut form of the halo tiles has one ring depth)
     if gn_in is not None:
         # GroupNorm of the input inside the launch: halo tiles only (the tile is normalised once in LDS); statistics from the producers
         q1, q2 = getattr(x, "qstats", None), (getattr(x2, "qstats", None) if x2 is not None else None)

@@ -652,6 +652,31 @@ def test_conv3x3_halo_split_k(ops, tile, shape, splits):
     close(to_nchw(yn), F.silu(F.group_norm(want, 32, gamma.cpu(), beta.cpu(), 1e-5)), rtol=3e-2)
 
 
+@pytest.mark.parametrize("tile,shape", [(15, (2, 125, 8)), (15, (2, 37, 16)), (16, (2, 125, 8)), (16, (3, 63, 4)), (16, (2, 37, 16))])
+@pytest.mark.parametrize("splits", [1, 2, 3])
+def test_conv3x3_halo_ws_fused_shortcut(ops, tile, shape, splits):
+    """conv2 + conv_shortcut of a ResnetBlock2D as ONE launch on the wave-specialised halo tiles (the 1x1 segment over x3 | x4 walks its
+    chunks as single-tap items with their own halo image, three halo buffers): == torch, whole and split-K (a split takes main chunks
+    AND a share of the segment's chunks; 3 splits of 2 main chunks leave the third without a main chunk only if the rule were wrong),
+    one or two segment sources, with the reduce deferred to a GroupNorm."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(150 + tile + splits)
+    h = bf(torch.randn(B, 192, H, W, generator=g))
+    xa, xb = bf(torch.randn(B, 128, H, W, generator=g)), bf(torch.randn(B, 64, H, W, generator=g))
+    w, b = bf(torch.randn(256, 192, 3, 3, generator=g) * 0.03), torch.randn(256, generator=g)
+    for two in (True, False):
+        cs = 192 if two else 128
+        ws_, bs_ = bf(torch.randn(256, cs, 1, 1, generator=g) * 0.06), torch.randn(256, generator=g)
+        xs = torch.cat([xa, xb], 1) if two else xa
+        want = F.conv2d(h, w, b, padding=1) + F.conv2d(xs, ws_, bs_)
+        pw = ops.pack_conv_shortcut(w.to(DEV), b.to(DEV), ws_.to(DEV), bs_.to(DEV))
+        y = ops.conv(nhwc(h), pw, pad=(1, 1), x3=nhwc(xa), x4=(nhwc(xb) if two else None), tile=tile, ring=3, splits=splits)
+        close(to_nchw(y), want)
+    gamma, beta = torch.randn(256, generator=g).to(DEV), torch.randn(256, generator=g).to(DEV)
+    yn = ops.conv(nhwc(h), pw, pad=(1, 1), x3=nhwc(xa), tile=tile, ring=3, splits=splits, gn=(gamma, beta, 32, 1e-5, ops.ACT_SILU))
+    close(to_nchw(yn), F.silu(F.group_norm(want, 32, gamma.cpu(), beta.cpu(), 1e-5)), rtol=3e-2)
+
+
 @pytest.mark.parametrize("tile,ring", [(13, 3), (13, 4), (14, 3), (14, 4), (13, 2), (14, 2)])   # ring 2 = register-staged loaders
 @pytest.mark.parametrize("kind", ["splitk_res", "plain_ragged", "shortcut_two_src", "shortcut_splitk", "one_by_one"])
 def test_conv_wave_specialised_small_tiles(ops, tile, ring, kind):

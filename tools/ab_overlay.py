@@ -152,8 +152,11 @@ for name, tile, ring, spdiv in rules:
         sp = base_used[k][2]
         if tile in (7, 8, 15, 16):
             ow = int(re.search(r" ow(\d+)", k).group(1))
-            if tile not in ops.halo_tiles(ow, True) or re.search(r" e\d+\+\d+", k):
+            if tile not in ops.halo_tiles(ow, True):
                 continue
+            if re.search(r" e\d+\+\d+", k):                # conv2 + conv_shortcut: wave-specialised halo tiles, three-pass halo, ring 3
+                if tile not in (15, 16) or ring != 3 or " up0 " not in k or (tile == 15 and (128 // ow + 2) * (ow + 2) > 192):
+                    continue
             nch = sum(int(v) for v in re.search(r" C(\d+)\+(\d+) ", k).groups()) // 64
             nsp = 1 if " gi" in k else max(1, min(nch, int(round(sp / spdiv))))
             if (nsp == sp and spdiv != 1) or (tile, ring, nsp) == tuple(base_used[k]):

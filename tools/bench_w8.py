@@ -4,14 +4,24 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audioldm_with_lora_amd import ops
 
-def run(name, B, H, W, Cin, Cout, cfgs, nrot=8):
+def run(name, B, H, W, Cin, Cout, cfgs, nrot=8, ext=0):
     g = torch.Generator().manual_seed(0)
     xs = [torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda() for _ in range(nrot)]
-    pws = [ops.pack_conv((torch.randn(Cout, Cin, 3, 3, generator=g) / 50).cuda(), torch.zeros(Cout).cuda()) for _ in range(nrot)]
+    if ext:      # conv2 + conv_shortcut over `ext` more channels of a second tensor (the fused 1x1 segment)
+        x3s = [torch.randn(B, H, W, ext, generator=g).to(torch.bfloat16).cuda() for _ in range(nrot)]
+        pws = [ops.pack_conv_shortcut((torch.randn(Cout, Cin, 3, 3, generator=g) / 50).cuda(), torch.zeros(Cout).cuda(),
+                                      (torch.randn(Cout, ext, 1, 1, generator=g) / 20).cuda(), torch.zeros(Cout).cuda()) for _ in range(nrot)]
+        conv0 = ops.conv
+        def conv_ext(x, pw, **kw):
+            return conv0(x, pw, x3=x3s[[id(t) for t in xs].index(id(x))], **kw)
+        ops_conv = conv_ext
+    else:
+        ops_conv = ops.conv
+        pws = [ops.pack_conv((torch.randn(Cout, Cin, 3, 3, generator=g) / 50).cuda(), torch.zeros(Cout).cuda()) for _ in range(nrot)]
     ref = None
     for (tile, ring, sp) in cfgs:
         try:
-            y = ops.conv(xs[0], pws[0], pad=(1, 1), tile=tile, ring=ring, splits=sp)
+            y = ops_conv(xs[0], pws[0], pad=(1, 1), tile=tile, ring=ring, splits=sp)
         except Exception as e:
             print(f"{name} tile {tile} ring {ring} splits {sp}: {str(e)[:80]}"); continue
         if ref is None:
@@ -21,7 +31,7 @@ def run(name, B, H, W, Cin, Cout, cfgs, nrot=8):
         with torch.cuda.graph(gr):
             for r in range(3):
                 for i in range(nrot):
-                    ops.conv(xs[i], pws[i], pad=(1, 1), tile=tile, ring=ring, splits=sp)
+                    ops_conv(xs[i], pws[i], pad=(1, 1), tile=tile, ring=ring, splits=sp)
         gr.replay(); torch.cuda.synchronize()
         best = 1e9
         for _ in range(5):
@@ -30,6 +40,12 @@ def run(name, B, H, W, Cin, Cout, cfgs, nrot=8):
             best = min(best, e0.elapsed_time(e1) / (3 * nrot))
         print(f"{name} tile {ops.TILE_NAMES[tile]:10s} ring {ring} splits {sp:2d}: {best * 1e3:7.2f} us (conv + reduce){'' if same else '  MISMATCH'}", flush=True)
 
+if len(sys.argv) > 1 and sys.argv[1] == "haloext":   # conv2 + conv_shortcut: the fused-shortcut halo-ws tiles against the generic ws tiles
+    run("M8000 N256 C256 e384", 8, 125, 8, 256, 256, [(13, 3, 2), (14, 3, 2), (15, 3, 2), (15, 3, 1), (16, 3, 1), (16, 3, 2)], ext=384)
+    run("M8000 N256 C256 e128", 8, 125, 8, 256, 256, [(14, 4, 1), (13, 3, 1), (15, 3, 1), (16, 3, 1), (15, 3, 2)], ext=128)
+    run("M32000 N128 C128 e256", 8, 250, 16, 128, 128, [(4, 3, 1), (13, 3, 1), (15, 3, 1), (16, 3, 1)], ext=256)
+    run("M2016 N384 C384 e640", 8, 63, 4, 384, 384, [(13, 3, 4), (16, 3, 3), (16, 3, 2), (16, 3, 4)], ext=640)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "halows":   # wave-specialised halo tiles (15, 16) against the plain halo tiles (7, 8)
     run("M512 N640 K5760", 8, 32, 2, 640, 640, [(14, 4, 6), (7, 3, 5), (15, 3, 5), (15, 4, 5), (15, 3, 10)])
     run("M2016 N384 K3456", 8, 63, 4, 384, 384, [(13, 3, 4), (7, 3, 3), (15, 3, 3), (15, 3, 6), (8, 3, 2), (16, 3, 2), (16, 3, 3), (16, 4, 3)])
