@@ -48,20 +48,6 @@ constexpr int KV = 64;           // keys per tile
 constexpr int VS = 136;          // V^T LDS row stride in bytes (64 keys * 2 B + 8 B pad): conflict-free ds_read_b64
 constexpr int VS8 = 72;          // the same for one-byte (e4m3) elements: 64 keys + 8 B pad
 
-// bf16 x 8 -> OCP e4m3 x 8 (the fp8 operand form of BASELINE config 5; saturating conversion v_cvt_pk_fp8_f32)
-__device__ __forceinline__ uint2 bf16x8_to_fp8(const bf16x8 v) {
-  const uint4 u = __builtin_bit_cast(uint4, v);
-  const unsigned w[4] = {u.x, u.y, u.z, u.w};
-  int o[2] = {0, 0};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-    if (i & 1) o[i >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, o[i >> 1], true);
-    else o[i >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, o[i >> 1], false);
-  }
-  return make_uint2((unsigned)o[0], (unsigned)o[1]);
-}
-__device__ __forceinline__ long pack2(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
 
 constexpr float RESCALE_THR = 5.0f;   // log2 units: the running max is raised only when a tile's max exceeds it by more than this
 

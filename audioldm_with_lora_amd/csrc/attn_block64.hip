@@ -52,7 +52,10 @@ struct Blk64Args {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int C, int D, int RT /* LoRA rank tiles of 16: 0, 1 or 2 */>
+// F8 (BASELINE config 5): Q / K / V / P enter the two attention products as OCP e4m3 (v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation); the
+// fragments are converted where they are used, from the same bf16-rounded values the two-launch fp8 path quantises, P carries 2^8 into
+// its conversion (e4m3 tops out at 448) and the normaliser sums the converted values, so the factor cancels exactly.
+template <int C, int D, int RT /* LoRA rank tiles of 16: 0, 1 or 2 */, bool F8 = false>
 __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(Blk64Args)>();
@@ -251,7 +254,13 @@ __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
       const char* krow = Ks + (16 * kt + n) * KSTR + (32 * ks + 4 * g) * 2;       // K[key 16 kt + n][dims 32 ks + 4 g .. | + 16 ..]
       const bf16x4 lo = *reinterpret_cast<const bf16x4*>(krow);
       const bf16x4 hi = (32 * ks + 16 < D) ? *reinterpret_cast<const bf16x4*>(krow + 32) : bf16x4{0, 0, 0, 0};
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), qf[ks], s[kt], 0, 0, 0);   // S^T[key 16 kt + 4 g + j][query n]
+      const bf16x8 kf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (F8) {
+        const uint2 k8 = bf16x8_to_fp8(kf), q8 = bf16x8_to_fp8(qf[ks]);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack2(k8.x, k8.y), pack2(q8.x, q8.y), s[kt], 0, 0, 0);
+      } else {
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);   // S^T[key 16 kt + 4 g + j][query n]
+      }
     }
   }
   B64_STAMP(21)
@@ -267,14 +276,25 @@ __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float l = 0.f;
   bf16x8 pf[2];
+  int p8[4] = {0, 0, 0, 0};                                   // F8: P of key tile kt as four e4m3 bytes (dword kt = B-operand half kt & 1 of k-step kt >> 1)
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < 4; ++kt) {
+    if constexpr (F8) {
+      const float e0 = __builtin_amdgcn_exp2f(s[kt][0] - mx + 8.f), e1 = __builtin_amdgcn_exp2f(s[kt][1] - mx + 8.f);
+      const float e2 = __builtin_amdgcn_exp2f(s[kt][2] - mx + 8.f), e3 = __builtin_amdgcn_exp2f(s[kt][3] - mx + 8.f);
+      p8[kt] = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, p8[kt], false);
+      p8[kt] = __builtin_amdgcn_cvt_pk_fp8_f32(e2, e3, p8[kt], true);
+      l += (__builtin_amdgcn_cvt_f32_fp8(p8[kt], 0) + __builtin_amdgcn_cvt_f32_fp8(p8[kt], 1)) +
+           (__builtin_amdgcn_cvt_f32_fp8(p8[kt], 2) + __builtin_amdgcn_cvt_f32_fp8(p8[kt], 3));
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16 pb = (bf16)__builtin_amdgcn_exp2f(s[kt][j] - mx);
-      l += (float)pb;                                         // the normaliser sums the SAME rounded values that multiply V
-      pf[kt >> 1][(kt & 1) * 4 + j] = pb;
+      for (int j = 0; j < 4; ++j) {
+        const bf16 pb = (bf16)__builtin_amdgcn_exp2f(s[kt][j] - mx);
+        l += (float)pb;                                       // the normaliser sums the SAME rounded values that multiply V
+        pf[kt >> 1][(kt & 1) * 4 + j] = pb;
+      }
     }
+  }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
@@ -290,7 +310,13 @@ __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
       const char* vrow = Vt + (16 * t + n) * VSTR + (32 * kk + 4 * g) * 2;      // V^T[16 t + n][keys 32 kk + 4 g .. | + 16 ..]
       const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
       const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf[kk], o, 0, 0, 0);
+      const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (F8) {
+        const uint2 v8 = bf16x8_to_fp8(vf);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack2(v8.x, v8.y), pack2((unsigned)p8[2 * kk], (unsigned)p8[2 * kk + 1]), o, 0, 0, 0);
+      } else {
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk], o, 0, 0, 0);
+      }
     }
     const bf16x4 ov = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
     if (live) *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = ov;   // O^T[d 16 t + 4 g + j][query n]
@@ -299,11 +325,11 @@ __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
 #endif
 }
 
-template <int C, int D, int RT>
+template <int C, int D, int RT, bool F8 = false>
 int launch_blk64(const Blk64Args& a, int B, hipStream_t st) {
   constexpr int LDS = 3 * (16 * C * 2 + 1024) + 64 * (D * 2 + 16) + D * (64 * 2 + 8) + 2 * 3 * D * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = attn_block64_kernel<C, D, RT>;
+  auto kern = attn_block64_kernel<C, D, RT, F8>;
   static unsigned long long attr_done = 0;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), LDS, &attr_done, "attn_block64")) return rc;
   hipLaunchKernelGGL(kern, dim3(a.H, B), dim3(256), LDS, st, a);
@@ -318,7 +344,7 @@ unsigned long long* g_b64_diag = nullptr;
 // debugging hook (tools/debug_b64.py), not part of the drop-in boundary: 24 x u64 device buffer for in-kernel time stamps
 extern "C" void aldm_attn_block64_set_diag(void* buf) { g_b64_diag = (unsigned long long*)buf; }
 
-extern "C" int aldm_attn_block64(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+static int attn_block64_entry(bool f8, const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
                                  const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used,
                                  const float* ln_sa, const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out,
                                  void* stream) {
@@ -330,7 +356,26 @@ extern "C" int aldm_attn_block64(const void* x, const float* ln_parts, int ln_np
   Blk64Args a{(const bf16*)x, ln_parts, (const bf16*)w, bias, ln_s, (const bf16*)lora_a, (const bf16*)lora_b, ln_sa, ln_ca, (bf16*)out,
               ln_nparts, Kpad, Rp, N, H, ln_eps, g_b64_diag};
   hipStream_t st = (hipStream_t)stream;
+  if (f8) {
+    if (Rp == 0) return launch_blk64<640, 80, 0, true>(a, B, st);
+    if (ranks_used <= 16) return launch_blk64<640, 80, 1, true>(a, B, st);
+    return launch_blk64<640, 80, 2, true>(a, B, st);
+  }
   if (Rp == 0) return launch_blk64<640, 80, 0>(a, B, st);
   if (ranks_used <= 16) return launch_blk64<640, 80, 1>(a, B, st);   // rank-4 q | k | v = 12 rows: one LoRA-A tile, the zero rows skipped
   return launch_blk64<640, 80, 2>(a, B, st);
+}
+
+extern "C" int aldm_attn_block64(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+                                 const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used,
+                                 const float* ln_sa, const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out,
+                                 void* stream) {
+  return attn_block64_entry(false, x, ln_parts, ln_nparts, w, Kpad, bias, ln_s, lora_a, lora_b, Rp, ranks_used, ln_sa, ln_ca, ln_eps, B, N, H, d, out, stream);
+}
+// config 5: the same launch with e4m3 Q / K / V / P attention operands (see F8 above)
+extern "C" int aldm_attn_block64_fp8(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+                                     const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used,
+                                     const float* ln_sa, const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out,
+                                     void* stream) {
+  return attn_block64_entry(true, x, ln_parts, ln_nparts, w, Kpad, bias, ln_s, lora_a, lora_b, Rp, ranks_used, ln_sa, ln_ca, ln_eps, B, N, H, d, out, stream);
 }

@@ -131,4 +131,17 @@ __device__ __forceinline__ void aldm_touch_kernargs() {
 #endif
 }
 
-
+// bf16 x 8 -> OCP e4m3 x 8 (the fp8 operand form of BASELINE config 5; v_cvt_pk_fp8_f32), and two dwords -> one 64-bit MFMA operand
+__device__ __forceinline__ uint2 bf16x8_to_fp8(const bf16x8 v) {
+  const uint4 u = __builtin_bit_cast(uint4, v);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+  int o[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+    if (i & 1) o[i >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, o[i >> 1], true);
+    else o[i >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, o[i >> 1], false);
+  }
+  return make_uint2((unsigned)o[0], (unsigned)o[1]);
+}
+__device__ __forceinline__ long pack2(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }

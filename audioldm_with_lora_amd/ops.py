@@ -958,11 +958,14 @@ def attn_block_ok(pw, N, H, d, ln_parts):
     return 0
 
 
-def attn_block(x2d, pw, ln_parts, B, N, H, d):
-    """x2d [B*N, C] raw hidden state -> attention output [B*N, C] through the fused launch attn_block_ok() names."""
+def attn_block(x2d, pw, ln_parts, B, N, H, d, fp8=False):
+    """x2d [B*N, C] raw hidden state -> attention output [B*N, C] through the fused launch attn_block_ok() names (fp8: config 5's e4m3
+    attention operands; the 64-token launch has that form, the 256-token one does not)."""
     kind = attn_block_ok(pw, N, H, d, ln_parts)
     if kind == 64:
-        return attn_block64(x2d, pw, ln_parts, B, N, H, d)
+        return attn_block64(x2d, pw, ln_parts, B, N, H, d, fp8=fp8)
+    if fp8:
+        raise _lib.AldmError("attn_block: the 256-token fused launch has no fp8 form")
     if kind != 256:
         raise _lib.AldmError(f"attn_block: no fused projection + attention launch for N {N}, {H} heads x {d}")
     _require_gpu(x2d)
@@ -978,7 +981,7 @@ def attn_block(x2d, pw, ln_parts, B, N, H, d):
     return out
 
 
-def attn_block64(x2d, pw, ln_parts, B, N, H, d):
+def attn_block64(x2d, pw, ln_parts, B, N, H, d, fp8=False):
     """x2d [B*N, C] raw hidden state -> attention output [B*N, C]: LayerNorm-folded QKV projection with LoRA + 64-token attention,
     one launch (aldm_attn_block64)."""
     _require_gpu(x2d)
@@ -987,7 +990,8 @@ def attn_block64(x2d, pw, ln_parts, B, N, H, d):
     assert ln_parts.dtype == torch.float32 and ln_parts.is_contiguous() and ln_parts.shape[0] == B * N
     out = torch.empty(B * N, Cc, dtype=torch.bfloat16, device=x2d.device)
     fl = B * (6.0 * N * Cc * Cc + 4.0 * N * N * Cc + (12.0 * N * Cc * getattr(pw, "ranks_used", 0) if pw.Rp else 0.0))
-    check(_launch(f"attn_block64_d{d}_n{N}", fl, 2.0 * (2 * B * N * Cc + 3 * Cc * Cc), lambda: _lib.load().aldm_attn_block64(
+    fn = _lib.load().aldm_attn_block64_fp8 if fp8 else _lib.load().aldm_attn_block64
+    check(_launch(f"attn_block64{'_fp8' if fp8 else ''}_d{d}_n{N}", fl, 2.0 * (2 * B * N * Cc + 3 * Cc * Cc), lambda: fn(
         _p(x2d), _p(ln_parts), ln_parts.shape[1], _p(pw.w), pw.Kpad, _p(pw.bias), _p(pw.ln_s), _p(pw.lora_a), _p(pw.lora_b), pw.Rp,
         getattr(pw, "ranks_used", 0) if pw.Rp else 0, _p(pw.ln_sa), _p(pw.ln_ca), pw.ln_eps, B, N, H, d, _p(out), _stream())),
         "aldm_attn_block64")

@@ -301,9 +301,11 @@ def run_attention(P, hn, h_res, B, N, fp8=False, ln_parts=None, rowstats=False):
     statistics of that sum for the LayerNorm that follows."""
     C = P.c
     ops.SITE = f"attn C{C} N{N}"                      # bench.py prices these launches as ONE fused-LoRA attention module (K1)
-    if not fp8 and ops.attn_block_ok(P.qkv, N, P.heads, P.d, ln_parts):
-        # the 64- and 252-token levels: projection (+ LoRA, folded LayerNorm) and attention of a (sample, head) in ONE launch; Q | K | V stay in LDS
-        a = ops.attn_block(hn, P.qkv, ln_parts, B, N, P.heads, P.d)
+    kind = ops.attn_block_ok(P.qkv, N, P.heads, P.d, ln_parts)
+    if kind == 64 or (kind and not fp8):
+        # the 64- and 252-token levels: projection (+ LoRA, folded LayerNorm) and attention of a (sample, head) in ONE launch; Q | K | V stay in
+        # LDS (config 5's e4m3 operands: the 64-token launch has an fp8 form, the 252-token one stays on the two launches)
+        a = ops.attn_block(hn, P.qkv, ln_parts, B, N, P.heads, P.d, fp8=fp8)
         y = ops.linear(a, P.out, res=h_res, rowstats=rowstats)
         ops.SITE = None
         return y

@@ -275,6 +275,11 @@ int aldm_attention_wide(const void* q, int ldq, const void* k, int ldk, const vo
 int aldm_attn_block64(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
                       const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used, const float* ln_sa,
                       const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out, void* stream);
+/* BASELINE config 5 for the same launch: Q / K / V / P enter the two attention products as OCP e4m3 (fp32 accumulation), quantised from the
+   bf16-rounded projection outputs exactly as aldm_attention_fp8 quantises them; everything else as aldm_attn_block64. */
+int aldm_attn_block64_fp8(const void* x, const float* ln_parts, int ln_nparts, const void* w, int Kpad, const float* bias,
+                          const float* ln_s, const void* lora_a, const void* lora_b, int Rp, int ranks_used, const float* ln_sa,
+                          const float* ln_ca, float ln_eps, int B, int N, int H, int d, void* out, void* stream);
 
 /* The same launch for the UNet's 252-token level (C = 384 = 8 heads x 48, N <= 256 tokens per sample: 63 x 4 for a 10 s clip, 64 x 4 in
    training): a (sample, head) workgroup of 8 waves keeps its tokens of X in registers, streams the head's 144 weight rows once and runs

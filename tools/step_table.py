@@ -1,5 +1,5 @@
 """One denoise step (config 2) as a table in launch order: label, K1 site, in-graph duration (kineto timestamps of replays).
-usage: python tools/step_table.py [batch]"""
+usage: python tools/step_table.py [batch] [fp8]       (fp8: config 5, e4m3 attention operands)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -8,6 +8,7 @@ from audioldm_with_lora_amd.scheduler import DDIMScheduler
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 unet, _ = bench.build_unet(4)
+unet.attention_fp8 = len(sys.argv) > 2 and sys.argv[2] == "fp8"
 eng = DenoiseEngine(unet, DDIMScheduler(), B, 250, 16, 200, 2.5)
 lat, pe, ne = bench.synth_inputs(B, 250, 16)
 eng.set_condition(pe, ne)
