@@ -43,7 +43,7 @@ def alternate(run, nprob=2, reps=REPS):
                 assert torch.equal(a, b), (k, rep, float((a.float() - b.float()).abs().max()))
 
 
-@pytest.mark.parametrize("tile,splits,stride", [(2, 1, 1), (4, 6, 1), (3, 1, 2), (1, 1, 1), (6, 1, 1)])
+@pytest.mark.parametrize("tile,splits,stride", [(2, 1, 1), (4, 6, 1), (3, 1, 2), (1, 1, 1), (6, 1, 1), (12, 1, 1), (13, 3, 1), (14, 4, 1), (13, 1, 2)])   # 12 - 14: the loader-wave tiles
 def test_conv_ring_padding_by_descriptor_range(ops, tile, splits, stride):
     """igemm_pipe_kernel: 3x3 taps whose padded positions are DMA'd as zeros (voffset 0x80000000), ragged M (rows past M clamped)"""
     g = torch.Generator().manual_seed(100 + tile)
@@ -56,8 +56,8 @@ def test_conv_ring_padding_by_descriptor_range(ops, tile, splits, stride):
     alternate(lambda k: (ops.conv(probs[k][0], probs[k][1], stride=(stride, stride), pad=(1, 1), tile=tile, splits=splits),))
 
 
-@pytest.mark.parametrize("tile,up", [(7, False), (8, False), (7, True)])
-def test_halo_kernel_zero_rows(ops, tile, up):
+@pytest.mark.parametrize("tile,up,splits", [(7, False, 1), (8, False, 1), (7, True, 1), (7, False, 2), (15, False, 1), (16, False, 2), (15, True, 1), (15, False, 2)])   # 15 / 16: loader waves
+def test_halo_kernel_zero_rows(ops, tile, up, splits):
     """igemm_halo_kernel: the halo's border rows / columns are OOB lanes of the LDS-DMA (zeros through the descriptor)"""
     g = torch.Generator().manual_seed(200 + tile)
     B, H, W, C1, C2, Cout = 2, (6 if up else 24), (8 if up else 16), 64, 64, 128
@@ -66,12 +66,28 @@ def test_halo_kernel_zero_rows(ops, tile, up):
         x1, x2 = dv(torch.randn(B, H, W, C1, generator=g)), dv(torch.randn(B, H, W, C2, generator=g) * 2)
         pw = ops.pack_conv((torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 30).to(DEV), torch.randn(Cout, generator=g).to(DEV))
         probs.append((x1, x2, pw))
-    kw = dict(pad=(1, 1), tile=tile, up_size=((2 * H, 2 * W) if up else None))
+    kw = dict(pad=(1, 1), tile=tile, splits=splits, up_size=((2 * H, 2 * W) if up else None))
     alternate(lambda k: (ops.conv(probs[k][0], probs[k][2], x2=probs[k][1], **kw),))
 
 
-def test_halo_kernel_groupnorm_of_the_input(ops):
-    """GNIN instantiation: the chunk is normalised in place between its vmcnt wait and the barrier that releases it"""
+@pytest.mark.parametrize("tile,splits", [(15, 1), (16, 1), (15, 2), (16, 3)])
+def test_halo_ws_fused_shortcut_segment(ops, tile, splits):
+    """igemm_halo_ws_kernel, EXT: single-tap items with their own halo image in a three-buffer rotation, loaders two items ahead"""
+    g = torch.Generator().manual_seed(250 + tile + splits)
+    B, H, W, C, Ce, Cout = 2, 24, 16, 128, 192, 128
+    probs = []
+    for k in range(2):
+        h, xa, xb = (dv(torch.randn(B, H, W, c, generator=g) * (1 + k)) for c in (C, 128, 64))
+        pw = ops.pack_conv_shortcut((torch.randn(Cout, C, 3, 3, generator=g) / 30).to(DEV), torch.randn(Cout, generator=g).to(DEV),
+                                    (torch.randn(Cout, Ce, 1, 1, generator=g) / 12).to(DEV), torch.randn(Cout, generator=g).to(DEV))
+        probs.append((h, xa, xb, pw))
+    alternate(lambda k: (ops.conv(probs[k][0], probs[k][3], pad=(1, 1), x3=probs[k][1], x4=probs[k][2], tile=tile, ring=3, splits=splits),))
+
+
+@pytest.mark.parametrize("tile", [0, 15, 16])
+def test_halo_kernel_groupnorm_of_the_input(ops, tile):
+    """GNIN instantiation: the chunk is normalised in place between its vmcnt wait and the barrier that releases it (tiles 15 / 16: by
+    the loader waves)"""
     g = torch.Generator().manual_seed(7)
     B, H, W, C, N = 2, 40, 16, 128, 128
     probs = []
@@ -88,7 +104,7 @@ def test_halo_kernel_groupnorm_of_the_input(ops):
         probs.append((y, pw, gm, bt))
     if not ops.gn_in_ok(probs[0][0], None, probs[0][1], (1, 1), (1, 1), (1, 1), None, None):
         pytest.skip("this geometry does not take the input-norm fold")
-    alternate(lambda k: (ops.conv(probs[k][0], probs[k][1], pad=(1, 1), gn_in=(probs[k][2], probs[k][3], 32, 1e-5, 1)),))
+    alternate(lambda k: (ops.conv(probs[k][0], probs[k][1], pad=(1, 1), tile=tile, gn_in=(probs[k][2], probs[k][3], 32, 1e-5, 1)),))
 
 
 @pytest.mark.parametrize("M,K,N,r", [(2016, 384, 384, 4), (512, 640, 640, 4), (8000, 256, 256, 4)])
