@@ -730,6 +730,14 @@ if os.path.exists(PGEMM_TUNED_PATH) and os.environ.get("ALDM_NO_TUNED") != "1":
             PGEMM_CFG[(int(_m), int(_n), int(_kk), _kind)] = tuple(_v)
 
 
+if os.environ.get("ALDM_PGEMM_PATCH"):                        # A/B aid: {"M|N|K|kind": [mi, nt, tpr, nw] | null (= no entry: the planner decides)}
+    with open(os.environ["ALDM_PGEMM_PATCH"]) as _f:
+        for _k, _v in json.load(_f).items():
+            _m, _n, _kk, _kind = _k.split("|")
+            if _v is None:
+                PGEMM_CFG.pop((int(_m), int(_n), int(_kk), _kind), None)
+            else:
+                PGEMM_CFG[(int(_m), int(_n), int(_kk), _kind)] = tuple(_v)
 PGEMM_USE_IGEMM = (0, 0, 0, 0)                               # table entry: this GEMM measured faster on aldm_igemm, keep it there
 
 
