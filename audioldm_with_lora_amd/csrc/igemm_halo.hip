@@ -92,7 +92,10 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmDev p) {
       const int hy = fdiv(hp, fd_w2), hx = hp - hy * HW2;
       const int gy = ty0 - 1 + hy, gx = hx - 1;
       const bool ok = hp < halo_rows && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      const int sy = up ? (gy >> 1) : gy, sx = up ? (gx >> 1) : gx;
+      // nearest up-sampling folded into the gather: exact 2x by a shift, any other size by the same floor(dst * in / out) the generic
+      // kernel applies (F.interpolate(size=(125, 8)) of a 63 x 4 latent); ok == false rows never use sy / sx
+      const int sy = !up ? gy : (p.UH == 2 * p.IH ? (gy >> 1) : (gy * p.IH) / p.UH);
+      const int sx = !up ? gx : (p.UW == 2 * p.IW ? (gx >> 1) : (gx * p.IW) / p.UW);
       h_pix[ps] = ok ? (img * p.IH + sy) * p.IW + sx : -1;
     }
   }
@@ -375,7 +378,10 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
         const int hy = fdiv(hp, fd_w2), hx = hp - hy * HW2;
         const int gy = ty0 - 1 + hy, gx = hx - 1;
         const bool ok = hp < halo_rows && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const int sy = up ? (gy >> 1) : gy, sx = up ? (gx >> 1) : gx;
+        // nearest up-sampling folded into the gather: exact 2x by a shift, any other size by the same floor(dst * in / out) the generic
+      // kernel applies (F.interpolate(size=(125, 8)) of a 63 x 4 latent); ok == false rows never use sy / sx
+      const int sy = !up ? gy : (p.UH == 2 * p.IH ? (gy >> 1) : (gy * p.IH) / p.UH);
+      const int sx = !up ? gx : (p.UW == 2 * p.IW ? (gx >> 1) : (gx * p.IW) / p.UW);
         h_pix[ps] = ok ? (img * p.IH + sy) * p.IW + sx : -1;
       }
     }
@@ -605,7 +611,7 @@ int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, h
   const bool ok = d.KH == 3 && d.KW == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh == 1 && d.dw == 1 &&
                   d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.dilate == 0 &&
                   !d.ln_s && !d.geglu && d.x_bytes < 0x80000000u && d.x2_bytes < 0x80000000u &&
-                  (d.UH == 0 || (d.UH == 2 * d.IH && d.UW == 2 * d.IW)) && d.OH == (d.UH ? d.UH : d.IH) && d.OW == (d.UW ? d.UW : d.IW);
+                  ((d.UH == 0 && d.UW == 0) || (d.UH > 0 && d.UW > 0)) && d.OH == (d.UH ? d.UH : d.IH) && d.OW == (d.UW ? d.UW : d.IW);
   if (!ok) {
     aldm_set_error("igemm_halo: needs a 3x3 / stride 1 / pad 1 conv on the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
     return ALDM_E_UNSUPPORTED;

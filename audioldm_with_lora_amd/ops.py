@@ -607,8 +607,7 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
         key = tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None, pw.geglu,
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
-                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None
-                          and (up_size is None or up_size == (2 * IH, 2 * IW)))
+                          and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None)   # (any nearest up-sampling size)
         if x3 is not None:      # conv2 + conv_shortcut as one GEMM: the wave-specialised halo tiles only, three-pass halo, no up-sampling
             halo = [t for t in halo if t in (15, 16) and up_size is None and C3 % 64 == 0 and C4 % 64 == 0
                     and (TILE_DIMS[t][0] // OW + 2) * (OW + 2) <= (192 if t == 15 else 128)]

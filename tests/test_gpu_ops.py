@@ -67,11 +67,13 @@ def test_conv3x3(ops, B, Cin, Cout, H, W, stride, tile):
     (1, 192, 0, 40, 10, 8, False),        # Cout below the tile width, 3 channel chunks
     (2, 64, 0, 64, 14, 16, True),         # nearest 2x up-sampling folded into the gather (7x8 -> 14x16)
     (1, 256, 128, 128, 250, 16, False),   # config-2 level-0 up-block conv of one image
+    (2, 128, 0, 128, 125, 8, (63, 4)),    # the UNet's 63 x 4 -> 125 x 8 up-sampler: nearest to a size that is not 2x
+    (2, 64, 64, 64, 13, 16, (5, 8)),      # 5 -> 13 rows (2.6x), 8 -> 16 columns, two sources
 ])
 def test_conv3x3_halo_tiles(ops, tile, B, C1, C2, Cout, H, W, up):
     """3x3/s1/p1 conv through the LDS-halo kernel == F.conv2d, incl. time-embedding row bias, residual and SiLU epilogue."""
     g = torch.Generator().manual_seed(7)
-    ih, iw = (H // 2, W // 2) if up else (H, W)
+    ih, iw = up if isinstance(up, tuple) else (H // 2, W // 2) if up else (H, W)
     x1 = bf(torch.randn(B, C1, ih, iw, generator=g))
     x2 = bf(torch.randn(B, C2, ih, iw, generator=g)) if C2 else None
     w = bf(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2)))
