@@ -190,7 +190,7 @@ extern "C" int aldm_igemm(const aldm_igemm_t* p, void* stream) {
       if (d.splits > 1) {   // split-K by whole 64-channel chunks: a chunk's halo serves its nine taps in one workgroup
         const int nch = (d.Cin + d.Cin2) / BK;
         const int cps = cdiv(nch, d.splits > nch ? nch : d.splits);
-        d.kt_per_split = 9 * cps;
+        d.kt_per_split = d.KH * d.KW * cps;
         d.splits = cdiv(nch, cps);
       }
       rc = aldm_launch_halo(d, tile, p->ring, st);

@@ -305,7 +305,11 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= NTC / 64;
   const int W = p.OW, H = p.OH;
-  const int HW2 = W + 2;
+  // General filter geometry (round 4, for the vocoder's dilated 1-D convolutions, which arrive re-interpreted as KH x 1 filters over a
+  // T x 1 image -- aldm_launch_halo): KH x KW taps with dilation (dh, dw), "same" padding (ph, pw), stride 1.  The halo of a tile of
+  // rows_pt image rows is (rows_pt + (KH - 1) dh) x (W + (KW - 1) dw) pixels; tap (kh, kw) reads it at row offset kh dh HW2 + kw dw.
+  const int KWt = p.KW, NTAP = p.KH * p.KW;
+  const int HW2 = W + (p.KW - 1) * p.dw;
   const int rows_pt = BM / W;
   const int tpi = (H + rows_pt - 1) / rows_pt;
   int wid = blockIdx.x, split = 0;
@@ -316,16 +320,17 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
   const int tile_m = fdiv(wid, p.fd_tiles_n), tile_n = wid - tile_m * p.tiles_n;
   const int img = tile_m / tpi, ty0 = (tile_m - img * tpi) * rows_pt;
   const int m0 = img * p.OHW + ty0 * W, n0 = tile_n * BN;
-  const int halo_rows = (rows_pt + 2) * HW2;
+  const int halo_rows = (rows_pt + (p.KH - 1) * p.dh) * HW2;
   const int nchunks = p.Ctot >> 6;
-  const int c_begin = EPI == 3 ? split * (p.kt_per_split / 9) : 0;
-  const int c_end = EPI == 3 ? min(nchunks, c_begin + p.kt_per_split / 9) : nchunks;
+  const int cps = EPI == 3 ? fdiv(p.kt_per_split, p.fd_kw) : 0;       // chunks per split; fd_kw here: / (KH KW), set by launch_halo_v
+  const int c_begin = EPI == 3 ? split * cps : 0;
+  const int c_end = EPI == 3 ? min(nchunks, c_begin + cps) : nchunks;
   // the segment's chunks of this workgroup: [e_begin, e_end) of C3tot / 64
   const int next = EXT ? (p.C3tot >> 6) : 0;
   const int eps = EPI == 3 ? (next + p.splits - 1) / p.splits : next;
   const int e_begin = EPI == 3 ? min(next, split * eps) : 0;
   const int e_end = min(next, e_begin + eps);
-  const int nmain = (c_end - c_begin) * 9;
+  const int nmain = (c_end - c_begin) * NTAP;
   const int nitems = nmain + (e_end - e_begin);
 
   if constexpr (GNIN) {
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
       for (int ps = 0; ps < HPL; ++ps) {
         const int hp = rbase + RPP * ps;
         const int hy = fdiv(hp, fd_w2), hx = hp - hy * HW2;
-        const int gy = ty0 - 1 + hy, gx = hx - 1;
+        const int gy = ty0 - p.ph + hy, gx = hx - p.pw;
         const bool ok = hp < halo_rows && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         // nearest up-sampling folded into the gather: exact 2x by a shift, any other size by the same floor(dst * in / out) the generic
       // kernel applies (F.interpolate(size=(125, 8)) of a 63 x 4 latent); ok == false rows never use sy / sx
@@ -422,13 +427,13 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
           }
         }
       }
-      const int ksoff = !live ? 0 : (EXT && i_ext) ? (9 * p.Ctot + (i_c << 6)) * 2 : (i_tap * p.Ctot + (i_c << 6)) * 2;
+      const int ksoff = !live ? 0 : (EXT && i_ext) ? (NTAP * p.Ctot + (i_c << 6)) * 2 : (i_tap * p.Ctot + (i_c << 6)) * 2;
 #pragma unroll
       for (int ps = 0; ps < W_PASSES; ++ps)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(bdst + ps * (RPP * 128)), 16, live ? b_off[ps] : OOB, ksoff, 0, 0);
       if (live) {
         if (EXT && i_ext) { ++i_c; ++i_u; }
-        else if (++i_tap == 9) {
+        else if (++i_tap == NTAP) {
           i_tap = 0; ++i_c; ++i_u;
           if (EXT && i_c == c_end) { i_ext = true; i_c = e_begin; }
         }
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
 #pragma unroll
       for (int d = 1; d < D; ++d) {
         const int t = c_tap + d, it = item + d;
-        const bool opens = it < nitems && (it >= nmain || (it < nmain && (t == 9 || t == 18)));
+        const bool opens = it < nitems && (it >= nmain || (it < nmain && (t == NTAP || t == 2 * NTAP)));
         young += opens ? 1 : 0;
       }
       if (young == 0) wait_vmcnt<(D - 1) * W_PASSES>();
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
       __builtin_amdgcn_s_barrier();                          // item handed over; the stage of item - 1 is free
       issue(item + D, st_fill);
       st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
-      if (item < nmain && ++c_tap == 9) { c_tap = 0; ++c_c; }
+      if (item < nmain && ++c_tap == NTAP) { c_tap = 0; ++c_c; }
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
       const bool seg = EXT && item >= nmain;                 // (uniform) an item of the 1x1 segment: centre tap of its own halo image
       const char* As = Hs + (EXT ? c_u % 3 : (c_c & 1)) * HALO_BYTES;
       const char* Bs = Bring + st * BSTAGE;
-      const int tap_off = seg ? HW2 + 1 : c_dy * HW2 + c_dx;
+      const int tap_off = seg ? HW2 + 1 : c_dy * p.dh * HW2 + c_dx * p.dw;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int ch = ks * 4 + lq;
@@ -528,8 +533,8 @@ __global__ __launch_bounds__(768) void igemm_halo_ws_kernel(const IgemmDev p) {
       st = (st + 1 == S) ? 0 : st + 1;
       if (seg) { ++c_u; continue; }
       ++c_tap;
-      if (++c_dx == 3) { c_dx = 0; ++c_dy; }
-      if (c_tap == 9) { c_tap = 0; c_dy = 0; ++c_c; ++c_u; }
+      if (++c_dx == KWt) { c_dx = 0; ++c_dy; }
+      if (c_tap == NTAP) { c_tap = 0; c_dy = 0; ++c_c; ++c_u; }
     }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -554,14 +559,16 @@ int launch_halo_v(const IgemmDev& d, hipStream_t st) {
   else kern = igemm_halo_kernel<BM, BN, WM, WN, HP, S, EPI, GNIN>;
   if (int rc = aldm_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds, &attr_done, "igemm_halo")) return rc;
   const int rows_pt = BM / d.OW;
-  if (BM % d.OW != 0 || (rows_pt + 2) * (d.OW + 2) > HP * 64) {
-    aldm_set_error("igemm_halo: image width %d does not fit the %dx%d halo tile", d.OW, BM, BN);
+  const int need = WS ? (rows_pt + (d.KH - 1) * d.dh) * (d.OW + (d.KW - 1) * d.dw) : (rows_pt + 2) * (d.OW + 2);
+  if (BM % d.OW != 0 || need > HP * 64) {
+    aldm_set_error("igemm_halo: image width %d / filter %dx%d does not fit the %dx%d halo tile (%d halo rows of %d)", d.OW, d.KH, d.KW, BM, BN, need, HP * 64);
     return ALDM_E_UNSUPPORTED;
   }
   IgemmDev dd = d;
+  if (WS) dd.fd_kw = make_fastdiv((unsigned)(d.KH * d.KW));    // the wave-specialised kernel: kt_per_split / taps = chunks per split
   dd.tiles_n = cdiv(d.N, BN);
   dd.fd_tiles_n = make_fastdiv((unsigned)dd.tiles_n);
-  dd.fd_halo = make_fastdiv((unsigned)(d.OW + 2));
+  dd.fd_halo = make_fastdiv((unsigned)(WS ? d.OW + (d.KW - 1) * d.dw : d.OW + 2));
   const int tpi = cdiv(d.OH, rows_pt);
   dd.tiles_m = d.B * tpi * dd.tiles_n;                      // (split-K form) tiles per split: the divisor that peels the split off blockIdx.x
   dd.fd_tiles_m = make_fastdiv((unsigned)dd.tiles_m);
@@ -606,14 +613,27 @@ int launch_halo(const IgemmDev& d, hipStream_t st) {
 }  // namespace aldm_igemm_detail
 
 // tile: ALDM_TILE_HALO_128x128 / _64x128 or their wave-specialised forms (_WS).  The caller (aldm_igemm) has validated the generic arguments.
-int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, hipStream_t st) {
+int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d0, int tile, int ring, hipStream_t st) {
   using namespace aldm_igemm_detail;
-  const bool ok = d.KH == 3 && d.KW == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh == 1 && d.dw == 1 &&
+  IgemmDev d = d0;
+  const bool ws = tile == ALDM_TILE_HALO_128x128_WS || tile == ALDM_TILE_HALO_64x128_WS;
+  if (ws && d.KH == 1 && d.OH == 1 && d.IH == 1 && d.UH == 0 && d.ph == 0 && d.dh == 1 && d.sh == 1 && d.C3tot == 0 && !d.gi_gamma) {
+    // a 1-D convolution (conv1d = KH 1 over a 1 x T image): the same memory read as a T x 1 image under a KW x 1 filter -- the tile is then
+    // BM consecutive time steps, its halo BM + (KW - 1) dw rows, the weight layout [(tap, c)] is unchanged
+    d.KH = d.KW; d.KW = 1; d.dh = d.dw; d.dw = 1; d.ph = d.pw; d.pw = 0;
+    d.OH = d.OW; d.OW = 1; d.IH = d.IW; d.IW = 1; d.sh = d.sw; d.sw = 1;
+    d.fd_ow = make_fastdiv(1u);
+    d.fd_ohw = make_fastdiv((unsigned)d.OHW);
+  }
+  const bool same = ws ? (d.KH % 2 == 1 && d.KW % 2 == 1 && 2 * d.ph == (d.KH - 1) * d.dh && 2 * d.pw == (d.KW - 1) * d.dw &&
+                          ((d.KH == 3 && d.KW == 3 && d.dh == 1 && d.dw == 1) || (d.C3tot == 0 && !d.gi_gamma && d.UH == 0)))
+                       : (d.KH == 3 && d.KW == 3 && d.ph == 1 && d.pw == 1 && d.dh == 1 && d.dw == 1);
+  const bool ok = same && d.sh == 1 && d.sw == 1 &&
                   d.in_act == ALDM_ACT_NONE && d.Cin % 64 == 0 && d.Cin2 % 64 == 0 && d.dilate == 0 &&
                   !d.ln_s && !d.geglu && d.x_bytes < 0x80000000u && d.x2_bytes < 0x80000000u &&
                   ((d.UH == 0 && d.UW == 0) || (d.UH > 0 && d.UW > 0)) && d.OH == (d.UH ? d.UH : d.IH) && d.OW == (d.UW ? d.UW : d.IW);
   if (!ok) {
-    aldm_set_error("igemm_halo: needs a 3x3 / stride 1 / pad 1 conv on the LDS-DMA path (Cin %% 64 == 0, no gather activation)");
+    aldm_set_error("igemm_halo: needs a stride-1 'same' convolution on the LDS-DMA path (Cin %% 64 == 0, no gather activation): 3x3, or -- wave-specialised tiles -- any odd filter with dilation");
     return ALDM_E_UNSUPPORTED;
   }
   if (d.C3tot > 0) {                                          // the fused 1x1 segment: wave-specialised tiles, three-pass halo at most
@@ -624,7 +644,7 @@ int aldm_launch_halo(const aldm_igemm_detail::IgemmDev& d, int tile, int ring, h
     return ALDM_E_UNSUPPORTED;
   }
   if (tile == ALDM_TILE_HALO_128x128_WS) {                  // 8 compute + 4 loader waves; ring 3 (4 where asked)
-    if ((128 / d.OW + 2) * (d.OW + 2) > 192) {
+    if ((128 / d.OW + (d.KH - 1) * d.dh) * (d.OW + (d.KW - 1) * d.dw) > 192) {
       if (ring == 4) return launch_halo<128, 128, 4, 2, 5, 4, true>(d, st);
       return launch_halo<128, 128, 4, 2, 5, 3, true>(d, st);
     }

@@ -608,6 +608,10 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
                        pw.ln_s is not None, fast_path, OW, pad, dil) + sfx
         halo = halo_tiles(OW, KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1) and dil == (1, 1) and fast_path
                           and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None)   # (any nearest up-sampling size)
+        if (KH == 1 and IH == 1 and KW % 2 == 1 and KW > 1 and stride == (1, 1) and pad == (0, (KW - 1) * dil[1] // 2) and dil[0] == 1 and fast_path
+                and not in_dilate and not pw.Rp and vt is None and not pw.geglu and pw.ln_s is None and up_size is None and x3 is None and gn_in is None):
+            # conv1d (the vocoder): the wave-specialised halo tiles read it as a KW x 1 filter over a T x 1 image (csrc/igemm_halo.hip)
+            halo = [t for t in (15, 16) if TILE_DIMS[t][0] + (KW - 1) * dil[1] <= HALO_ROWS[t]]
         if x3 is not None:      # conv2 + conv_shortcut as one GEMM: the wave-specialised halo tiles only, three-pass halo, no up-sampling
             halo = [t for t in halo if t in (15, 16) and up_size is None and C3 % 64 == 0 and C4 % 64 == 0
                     and (TILE_DIMS[t][0] // OW + 2) * (OW + 2) <= (192 if t == 15 else 128)]

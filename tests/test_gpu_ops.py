@@ -663,6 +663,35 @@ def test_conv3x3_halo_split_k(ops, tile, shape, splits):
     close(to_nchw(yn), F.silu(F.group_norm(want, 32, gamma.cpu(), beta.cpu(), 1e-5)), rtol=3e-2)
 
 
+@pytest.mark.parametrize("tile", [15, 16])
+@pytest.mark.parametrize("K,dil,T,C,N", [(3, 1, 1500, 128, 128), (7, 3, 1000, 128, 256), (11, 5, 777, 256, 128), (11, 1, 2000, 64, 64), (7, 5, 130, 128, 128)])
+def test_conv1d_dilated_on_halo_ws_tiles(ops, tile, K, dil, T, C, N):
+    """the vocoder's dilated 1-D convolutions on the wave-specialised halo tiles (read as a K x 1 filter over a T x 1 image: the tile's
+    BM time steps + (K - 1) dil halo rows are fetched once per 64-channel chunk instead of once per tap): == torch for the HiFi-GAN
+    residual-block geometries (K 3 / 7 / 11, dilation 1 / 3 / 5), T that does not fill the last tile, a clip boundary inside the
+    batch, the residual + second (leaky-ReLU'd) output epilogue of the block, and split-K."""
+    if tile == 16 and 64 + (K - 1) * dil > 128:
+        pytest.skip("halo of this filter exceeds the 64-row tile's two DMA passes")
+    g = torch.Generator().manual_seed(160 + K + dil)
+    B = 3
+    x = bf(torch.randn(B, C, 1, T, generator=g))
+    w, b = bf(torch.randn(N, C, 1, K, generator=g) / math.sqrt(K * C)), torch.randn(N, generator=g)
+    pad = (K - 1) * dil // 2
+    want = F.conv2d(x, w, b, padding=(0, pad), dilation=(1, dil))
+    pw = ops.pack_conv(w.to(DEV), b.to(DEV))
+    y = ops.conv(nhwc(x), pw, pad=(0, pad), dil=(1, dil), tile=tile)
+    close(to_nchw(y), want)
+    r = bf(torch.randn(B, N, 1, T, generator=g))
+    out2 = torch.empty(B, 1, T, N, dtype=torch.bfloat16, device=DEV)
+    y = ops.conv(nhwc(x), pw, pad=(0, pad), dil=(1, dil), tile=tile, res=nhwc(r), out2=out2, post_act=ops.ACT_LRELU, post_slope=0.1)
+    close(to_nchw(y), want + r)
+    close(to_nchw(out2), F.leaky_relu(bf(want + r), 0.1), rtol=2e-2)
+    if C >= 128:
+        close(to_nchw(ops.conv(nhwc(x), pw, pad=(0, pad), dil=(1, dil), tile=tile, splits=2)), want)
+    base = ops.conv(nhwc(x), pw, pad=(0, pad), dil=(1, dil), tile=2)
+    assert float((ops.conv(nhwc(x), pw, pad=(0, pad), dil=(1, dil), tile=tile).float() - base.float()).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("tile,shape", [(15, (2, 125, 8)), (15, (2, 37, 16)), (16, (2, 125, 8)), (16, (3, 63, 4)), (16, (2, 37, 16))])
 @pytest.mark.parametrize("splits", [1, 2, 3])
 def test_conv3x3_halo_ws_fused_shortcut(ops, tile, shape, splits):

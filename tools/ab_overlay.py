@@ -34,7 +34,8 @@ def eligible(key):
         return False
     if family == "halo" and " gi" in key and " d0 " in key:
         return True                                         # GroupNorm-of-the-input launches: halo tiles only, never split
-    if any(t in key for t in (" gi", " lp", " rs", " vd")) or (family != "all" and " k3x3 s1 " not in key) or (family == "halo" and " d0 " not in key):
+    conv1d = family == "halo" and re.search(r" k1x(3|5|7|11) s1 up0 d0 ", key) is not None
+    if any(t in key for t in (" gi", " lp", " rs", " vd")) or (family != "all" and " k3x3 s1 " not in key and not conv1d) or (family == "halo" and " d0 " not in key):
         return False
     M = key_m(key)
     return (256 <= M <= 8192) if family == "small" else M > 8192 if family == "big" else M >= 256
@@ -126,7 +127,38 @@ def measure_vae(overlay, total=False):
     return per_key, tot, tot
 
 
-if workload == "vae":
+def measure_voc(overlay, total=False):
+    """SpeechT5HifiGan.forward of 4 x 10 s mels, eager, hipEvent pairs queued behind a sleep kernel."""
+    from audioldm_with_lora_amd.vocoder import SpeechT5HifiGan
+    ops.TUNED.clear(); ops.TUNED.update(BASE); ops.TUNED.update(overlay)
+    global _voc
+    if "_voc" not in globals():
+        torch.manual_seed(0)
+        _voc = SpeechT5HifiGan().cuda()
+    mel = torch.randn(4, 1, 1000, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)).to(torch.bfloat16)
+    for _ in range(2):
+        _voc.forward_nhwc(mel)
+    torch.cuda.synchronize()
+    ops.PROFILE, ops.KEYLOG = [], []
+    ops.sleep_us(100000)
+    _voc.forward_nhwc(mel)
+    torch.cuda.synchronize()
+    rows, keylog, ops.PROFILE, ops.KEYLOG = ops.PROFILE, dict(ops.KEYLOG), None, None
+    per_key, tot = {}, 0.0
+    for i, r in enumerate(rows):
+        us = r[3].elapsed_time(r[4]) * 1e3
+        tot += us
+        k, cfg = keylog.get(i, (None, None))
+        if k is not None:
+            per_key[k] = per_key.get(k, 0.0) + us
+            USED[k] = cfg
+    return per_key, tot, tot
+
+
+if workload == "voc":
+    measure = lambda ov, total=False: measure_voc(ov, total)
+    base_keys, base_tot, base_span = measure({})
+elif workload == "vae":
     measure = lambda ov, total=False: measure_vae(ov, total)
     base_keys, base_tot, base_span = measure({})
 elif workload == "train":
@@ -152,7 +184,11 @@ for name, tile, ring, spdiv in rules:
         sp = base_used[k][2]
         if tile in (7, 8, 15, 16):
             ow = int(re.search(r" ow(\d+)", k).group(1))
-            if tile not in ops.halo_tiles(ow, True):
+            m1 = re.search(r" k1x(\d+) s1 .* dl1x(\d+)", k)
+            if m1:                                              # conv1d: the wave-specialised halo tiles, halo = BM + (K - 1) dil rows
+                if tile not in (15, 16) or ops.TILE_DIMS[tile][0] + (int(m1.group(1)) - 1) * int(m1.group(2)) > ops.HALO_ROWS[tile]:
+                    continue
+            elif tile not in ops.halo_tiles(ow, True):
                 continue
             if re.search(r" e\d+\+\d+", k):                # conv2 + conv_shortcut: wave-specialised halo tiles, three-pass halo, ring 3
                 if tile not in (15, 16) or ring != 3 or " up0 " not in k or (tile == 15 and (128 // ow + 2) * (ow + 2) > 192):
