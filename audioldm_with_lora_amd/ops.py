@@ -7,6 +7,7 @@ import ctypes as C
 import json
 import math
 import os
+import sys
 from dataclasses import dataclass
 from typing import Optional
 
@@ -620,6 +621,8 @@ def conv(x: torch.Tensor, pw: PackedW, *, x2: Optional[torch.Tensor] = None, str
             cfg = TUNED.get(tune_key(M, pw.N, C1, C2, KH, KW, stride, up_size is not None, in_dilate, pw.Rp, vt is not None,
                                      pw.geglu, pw.ln_s is not None, fast_path) + sfx)
         if cfg is not None and cfg[0] in HALO_ROWS and cfg[0] not in halo:
+            if os.environ.get("ALDM_VERBOSE_TUNED") == "1":
+                print(f"[ops] table entry {cfg} of '{key}' names a halo tile this geometry cannot take: heuristics instead", file=sys.stderr)
             cfg = None                                  # never trust a table entry into a tile this geometry cannot take
         tuning = TUNER is not None and not torch.cuda.is_current_stream_capturing()
         if tuning:
