@@ -135,10 +135,12 @@ typedef struct {
 enum { ALDM_TILE_AUTO = 0, ALDM_TILE_128x128 = 1, ALDM_TILE_64x64 = 2, ALDM_TILE_128x64 = 3, ALDM_TILE_64x128 = 4,
        ALDM_TILE_32x64 = 5, ALDM_TILE_128x128_W8 = 6 /* 8-wave workgroup */,
        /* 3x3 / stride-1 / pad-1 convs only: the workgroup keeps the input halo of BM/OW image rows in LDS and reads the
-          nine taps from it (csrc/igemm_halo.hip); needs Cin % 64 == 0, BM % OW == 0, no split-K / LoRA / V^T */
+          nine taps from it (csrc/igemm_halo.hip); needs Cin % 64 == 0, BM % OW == 0, no LoRA / V^T; split-K by 64-channel chunk */
        ALDM_TILE_HALO_128x128 = 7, ALDM_TILE_HALO_64x128 = 8,
        ALDM_TILE_HALO_128x128_WS = 15, ALDM_TILE_HALO_64x128_WS = 16 /* the halo tiles with 8 compute + 4 loader waves (the loader waves also
-          apply gnin_*) */,
+          apply gnin_*).  Beyond 3x3: any odd KH x KW filter with dilation and "same" padding at stride 1, nearest up-sampling to any size,
+          x3 | x4 (conv2 + conv_shortcut as one launch; ring 3, halo of at most three DMA passes), and conv1d (KH = 1, IH = OH = 1: read as a
+          KW x 1 filter over an IW x 1 image -- SpeechT5HifiGan's dilated residual-block convolutions) */,
        ALDM_TILE_256x128_W8 = 9 /* 8-wave workgroup, 64x64 per wave: big-M plain convolutions (VAE, vocoder) */,
        ALDM_TILE_256x128_WS = 12 /* wave-specialised: 8 compute waves + 4 loader waves that only feed the LDS-DMA ring (csrc/igemm_ws.hip);
           plain big-M convolutions: LDS-DMA path, no LoRA / V^T / folded LayerNorm / fused 1x1 segment / GEGLU */,
