@@ -798,6 +798,9 @@ def _pgemm(x, pw, out, out_ld, M, K, OHW, res, vt, vt_col0, vt_ld, vt_bs, rowsta
              f"|M{M} N{pw.N} K{K}{' geglu' if pw.geglu else ''}")
     if hasattr(out, "qstats"):
         del out.qstats                                       # (see conv(): never leave a stale GroupNorm table on a rewritten buffer)
+    if KEYLOG is not None and PROFILE is not None:
+        KEYLOG.append((len(PROFILE), ("pg:" + "|".join(str(v) for v in _pgemm_key(M, pw, K, res, vt, rowstats, lora_t_out is not None, vt_dual)),
+                                      (a.mi, a.nt, a.tiles_per_range, a.waves))))
     check(_launch(label, flops, nbytes, lambda: lib.aldm_pgemm(C.byref(a), _stream())), "aldm_pgemm")
     return (out, stats) if rowstats else out
 
