@@ -49,6 +49,7 @@ constexpr int VS = 136;          // V^T LDS row stride in bytes (64 keys * 2 B +
 constexpr int VS8 = 72;          // the same for one-byte (e4m3) elements: 64 keys + 8 B pad
 
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float RESCALE_THR = 5.0f;   // log2 units: the running max is raised only when a tile's max exceeds it by more than this
 
 __device__ __forceinline__ float max3f(float a, float b, float c) {
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
   // VALU instructions (and under the SIMD's other wave), and this loop is VALU-issue-bound -- 4 x 8 issue cycles replace 16 packed adds.
   constexpr bool ML = Cfg::VL && ATTN_ML;
   float l_run = 0.f;                            // VL without ML: this lane's share of l (its 32 keys of every tile), VALU adds
+  f32x2 l_pk = {0.f, 0.f};                      // ... accumulated as a PAIR (v_pk_add_f32: one instruction per two probabilities), folded into l_run per tile
   f32x16 lacc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #pragma unroll
           for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
         } else if constexpr (Cfg::VL) {
-          l_run *= alpha;
+          l_pk *= alpha;
         }
       }
       if (PRESCALED) {
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
 #define P0 p0
 #define P1 p1
 #endif
-        if constexpr (Cfg::VL && !ML) l_run += p0 + p1;
+        if constexpr (Cfg::VL && !ML) l_pk += f32x2{p0, p1};
         if constexpr (FP8) {
           pw8[i >> 2] = (i & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(P0, P1, pw8[i >> 2], true) : __builtin_amdgcn_cvt_pk_fp8_f32(P0, P1, pw8[i >> 2], false);
         } else {
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
     iteration(it, Set0{});
     if (it + 1 < niter) iteration(it + 1, Set1{});
   }
+  if constexpr (Cfg::VL && !ML) l_run = l_pk[0] + l_pk[1];
 
   if constexpr (SP > 1) {
     // ---- merge the key groups: groups 1.. leave (m, l, O^T) in LDS (the staging buffers are dead after the last barrier),
