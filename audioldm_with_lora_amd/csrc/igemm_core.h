@@ -275,6 +275,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   // compact code (with the statistics code compiled into every LEAN epilogue the short-K GEMMs ran 0.3-0.7 us slower each)
   constexpr bool LEAN = EPI == 1 || EPI == 4, GLEAN = EPI == 2, SLEAN = EPI == 3;   // 3: split-K launches -- only the partial-tile store
   constexpr bool QS = EPI == 0 || EPI == 4;
+  if constexpr (SLEAN) {
+    // Split-K partial tile straight from the accumulators: with the swapped MFMA a lane holds 4 consecutive channels of one pixel row, so
+    // the fp32 partials leave as 16-byte stores (four lanes = 64 contiguous bytes of a row) without the LDS transposition and its two
+    // barriers -- the consumer (igemm_reduce_kernel / the deferred GroupNorm) reads the slab row-major either way.
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm_off + i * 16 + lrow;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn_off + j * 16 + lq * 4;
+        if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(p.ws + ((long long)split * p.ws_rows + m) * p.N + n) = acc[i][j];   // (N % 4 == 0, host-checked)
+      }
+    }
+    return;
+  }
   float* Cs = reinterpret_cast<float*>(smem);
   if constexpr (LEAN && !VT) lnst = nullptr;               // LEAN keeps the V^T tile and the LayerNorm fold only in VT kernels
 
