@@ -94,6 +94,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16* __restri
                                                             bf16* __restrict__ out, int out_ld, float* __restrict__ lse,
                                                             const int* __restrict__ kv_len) {
   aldm_touch_kernargs<96>();                // 88 bytes of explicit arguments: both lines in one round (common.h)
+#ifndef ALDM_NO_KA_PREFETCH
+  aldm_prefetch_next_kernargs<96>(threadIdx.x);
+#endif
   using Cfg = AttnCfg<DP, FP8>;
   constexpr int T = 64 * NW;
   constexpr int DK = Cfg::DK, DT = Cfg::DT, KS = Cfg::KS, VS = Cfg::VSB;   // (VS shadows the bf16 stride: every use below is per-format)

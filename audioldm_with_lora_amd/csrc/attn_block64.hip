@@ -59,6 +59,9 @@ template <int C, int D, int RT /* LoRA rank tiles of 16: 0, 1 or 2 */, bool F8 =
 __global__ __launch_bounds__(256) void attn_block64_kernel(const Blk64Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   aldm_touch_kernargs<sizeof(Blk64Args)>();
+#ifndef ALDM_NO_KA_PREFETCH
+  aldm_prefetch_next_kernargs<sizeof(Blk64Args)>(threadIdx.x);
+#endif
   constexpr int NTOK = 64, CPR = C / 8;                      // 16-byte chunks per row
   constexpr int KSTEPS = C / 32;
   constexpr int DTL = D / 16;                                 // 16-column tiles per q / k / v section

@@ -145,3 +145,23 @@ __device__ __forceinline__ uint2 bf16x8_to_fp8(const bf16x8 v) {
   return make_uint2((unsigned)o[0], (unsigned)o[1]);
 }
 __device__ __forceinline__ long pack2(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
+
+// Warm the NEXT launch's kernel-argument segment in this XCD's L2.  In a captured hipGraph (and in the eager kernarg ring) the segments of
+// consecutive launches sit back to back in device memory (tools/micro/kernarg_probe.hip: 640-byte stride for a 584-byte struct, fixed
+// addresses across replays), and every launch starts by fetching its own, L2-cold, segment (aldm_touch_kernargs: one round trip, but a
+// full one).  Called once per workgroup AFTER the main loop, by threads t = 0 .. 23: lane t reads one dword of the t-th 64-byte line
+// behind this launch's segment -- 1.5 KB, the next one to three segments -- so that the lines arrive under this launch's epilogue and are
+// still resident when the next launch touches them.  Never crosses out of the 4 KB page of this launch's own segment (the pool's end
+// is the only place where the bytes behind a segment may be unmapped); the values are discarded.
+template <int BYTES>
+__device__ __forceinline__ void aldm_prefetch_next_kernargs(int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (t < 24) {
+    const char* ka = reinterpret_cast<const char*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const char* a = ka + ((BYTES + 127) & ~127) + t * 64;
+    if (((reinterpret_cast<unsigned long long>(a) ^ reinterpret_cast<unsigned long long>(ka)) >> 12) != 0) a = ka;
+    const unsigned v = *reinterpret_cast<const volatile unsigned*>(a);
+    (void)v;
+  }
+#endif
+}

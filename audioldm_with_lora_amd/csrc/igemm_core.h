@@ -275,6 +275,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDev& p, f32x4 (&acc)[M
   // compact code (with the statistics code compiled into every LEAN epilogue the short-K GEMMs ran 0.3-0.7 us slower each)
   constexpr bool LEAN = EPI == 1 || EPI == 4, GLEAN = EPI == 2, SLEAN = EPI == 3;   // 3: split-K launches -- only the partial-tile store
   constexpr bool QS = EPI == 0 || EPI == 4;
+#ifndef ALDM_NO_KA_PREFETCH
+  aldm_prefetch_next_kernargs<sizeof(IgemmDev)>(tid);        // under the epilogue: the next launch's argument segment into this XCD's L2
+#endif
   if constexpr (SLEAN) {
     // Split-K partial tile straight from the accumulators: with the swapped MFMA a lane holds 4 consecutive channels of one pixel row, so
     // the fp32 partials leave as 16-byte stores (four lanes = 64 contiguous bytes of a row) without the LDS transposition and its two

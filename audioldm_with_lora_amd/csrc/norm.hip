@@ -110,6 +110,9 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_reg_kernel(const bf16* _
                                                                    const float* __restrict__ beta, int act,
                                                                    bf16* __restrict__ y, AldmDiv dqpp) {
   aldm_touch_kernargs<96>();                // 84 bytes of explicit arguments: both lines in one round (common.h)
+#ifndef ALDM_NO_KA_PREFETCH
+  aldm_prefetch_next_kernargs<96>(threadIdx.x);
+#endif
   __shared__ float red[2 * GN_THREADS / 64];
   __shared__ __attribute__((aligned(16))) float sgm[GN_MAXCG], sbt[GN_MAXCG];
   const int C = C1 + C2;
@@ -188,6 +191,9 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_partials_kernel(const fl
                                                                         const float* __restrict__ beta, int act,
                                                                         bf16* __restrict__ y, AldmDiv dqpp) {
   aldm_touch_kernargs<160>();               // 148 bytes of explicit arguments: all three lines in one round (common.h)
+#ifndef ALDM_NO_KA_PREFETCH
+  aldm_prefetch_next_kernargs<160>(threadIdx.x);
+#endif
   // C = channels of the partial tiles (first source); C2 more channels come as plain bf16 from x2 (torch.cat([h, skip]) in
   // front of an up-block ResnetBlock2D's norm1).  A group lies wholly in one source (host-checked: C % group width == 0).
   __shared__ float red[2 * GN_THREADS / 64];

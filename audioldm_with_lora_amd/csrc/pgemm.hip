@@ -160,6 +160,9 @@ __global__ __launch_bounds__(64 * NW) void pgemm_kernel(const bf16* __restrict__
     ka_ptr_t ka = (ka_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka) : : "memory");
     aldm_touch_kernargs<PG_STRUCT_OFFSET + sizeof(PgArgs)>();   // every 64-byte line of the segment in ONE round trip (common.h)
+#ifndef ALDM_NO_KA_PREFETCH
+    aldm_prefetch_next_kernargs<PG_STRUCT_OFFSET + sizeof(PgArgs)>(threadIdx.x);
+#endif
     typedef const PgArgs __attribute__((address_space(4))) * pa_ptr_t;
     pa_ptr_t ps = (pa_ptr_t)(ka + PG_STRUCT_OFFSET);
     p.lora_a = ps->lora_a; p.lora_b = ps->lora_b; p.bias = ps->bias; p.ln_s = ps->ln_s; p.ln_sa = ps->ln_sa; p.ln_ca = ps->ln_ca;
