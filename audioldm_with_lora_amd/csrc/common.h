@@ -157,7 +157,10 @@ template <int BYTES>
 __device__ __forceinline__ void aldm_prefetch_next_kernargs(int t) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (t < 24) {
-    const char* ka = reinterpret_cast<const char*>(__builtin_amdgcn_kernarg_segment_ptr());
+    unsigned long long kau = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(kau));                            // (keep the segment pointer a scalar of its own: the per-lane address below must
+                                                             //  not drag the pointer other code hands to scalar loads into VGPRs)
+    const char* ka = reinterpret_cast<const char*>(kau);
     const char* a = ka + ((BYTES + 127) & ~127) + t * 64;
     if (((reinterpret_cast<unsigned long long>(a) ^ reinterpret_cast<unsigned long long>(ka)) >> 12) != 0) a = ka;
     const unsigned v = *reinterpret_cast<const volatile unsigned*>(a);
